@@ -1,0 +1,244 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the fused forward path (8x8 DCT + quantise + zigzag).
+
+Contract (driver): ``python bench.py --gpus N --steps K --warmup W`` prints ONE JSON line on
+rank 0.  For N > 1 it is launched under ``torch.distributed.run`` (one process per GPU, RCCL).
+
+Workload (BASELINE.json configs[1]): 4096x4096 synthetic Y planes, fp32, JPEG luminance table.
+A *step* is one fused-kernel launch over a batch of ``--planes`` DISTINCT 4096x4096 planes that
+are already resident in HBM (stacked as one tall plane = one launch).  16 planes = 1 GiB read +
+0.5 GiB written per step, far beyond the 256 MiB Infinity Cache, so the stream comes from HBM.
+Weak scaling: every rank owns its own batch (planes are independent units, no data-path
+collective in the timed region); the RCCL gather of the coefficient stream to rank 0 is timed
+separately and reported under "gather".
+
+value    = blocks processed by all ranks / max-over-ranks wall time of the K steps   [Mblocks/s]
+roofline = algorithmic bytes (384 B per block: 256 B fp32 read + 128 B int16 written) per launch
+           divided by the average launch duration measured with HIP events on the launch stream.
+cpu_baseline (rank 0, N=1 only) = the faithful Python/NumPy per-block loop restatement of the
+           reference (oracle/ref_loop.py, 1 core) on one plane; the C oracle's rate is given too.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "implementing-jpeg-compression_amd"))
+
+BYTES_PER_BLOCK = 384          # 64*4 B read + 64*2 B written
+HBM_PEAK_GBPS = 8000.0         # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--planes", type=int, default=16, help="distinct 4096x4096 planes per step and rank")
+    ap.add_argument("--size", type=int, default=4096)
+    ap.add_argument("--kind", default="noise", choices=["noise", "smooth"],
+                    help="synthetic plane generator (noise = worst case for rounding ties)")
+    ap.add_argument("--mode", default="qtable", choices=["qtable", "none", "divide", "discard"])
+    ap.add_argument("--param", type=float, default=0.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--no-gather", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(size, kind):
+    """Reference-shaped CPU pipeline on this host, single core (the reference is single-threaded)."""
+    import oracle
+    from oracle import ref_loop
+    from jpegx import synth
+    plane = synth.generate_plane(kind, size, size, seed=0, plane=0)
+    nblk = (size // 8) ** 2
+    ref_loop.forward_qtable(plane[:64, :64].astype(np.float64))          # warm-up
+    t0 = time.perf_counter()
+    zz_py = ref_loop.forward_qtable(plane.astype(np.float64))
+    t_py = time.perf_counter() - t0
+    best_c = None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        zz_c = oracle.forward_f32(plane, "qtable")
+        dt = time.perf_counter() - t0
+        best_c = dt if best_c is None else min(best_c, dt)
+    agree = int(np.count_nonzero(zz_py.astype(np.int16) != zz_c))
+    cores_avail = os.cpu_count()
+    try:
+        with open("/proc/cpuinfo") as f:
+            model = [l.split(":", 1)[1].strip() for l in f if l.startswith("model name")][0]
+    except Exception:
+        model = "unknown"
+    return {
+        "value": round(nblk / t_py / 1e6, 6), "unit": "Mblocks/s", "cores": 1, "kind": "port",
+        "sample": "one %dx%d %s plane (%d blocks), oracle/ref_loop.py per-block Python/NumPy loop "
+                  "(reference call structure), %.1f s" % (size, size, kind, nblk, t_py),
+        "c_oracle_mblocks_per_s": round(nblk / best_c / 1e6, 4),
+        "c_oracle_note": "oracle/jpegx_oracle.c, scalar C in the reference's fp64 order, 1 core, best of 3",
+        "python_vs_c_mismatches": agree, "host_cpu": model, "host_cores_available": cores_avail,
+    }
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
+                         % (args.gpus, args.gpus))
+
+    import jpegx
+    jpegx.require_device()
+    L = jpegx.lib()
+
+    dist = None
+    torch = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    jpegx.check(L.jpegx_set_device(local_rank if world > 1 else 0), "jpegx_set_device")
+
+    size, planes = args.size, args.planes
+    H, W = size * planes, size
+    blocks_per_step = (H // 8) * (W // 8)
+    in_bytes, out_bytes = H * W * 4, H * W * 2
+
+    if torch is not None:
+        t_in = torch.empty(H * W, dtype=torch.float32, device="cuda")
+        t_out = torch.empty(H * W, dtype=torch.int16, device="cuda")
+        in_ptr, out_ptr = t_in.data_ptr(), t_out.data_ptr()
+        stream = torch.cuda.current_stream().cuda_stream or None
+    else:
+        b_in, b_out = jpegx.DeviceBuffer(in_bytes), jpegx.DeviceBuffer(out_bytes)
+        in_ptr, out_ptr = b_in.ptr, b_out.ptr
+        stream = None
+
+    # synthetic planes generated on the device; plane ids are globally unique across ranks
+    for p in range(planes):
+        jpegx.generate_plane_device(in_ptr + p * size * size * 4, size, size, args.kind, seed=0,
+                                    plane=rank * planes + p, stream=stream)
+    jpegx.check(L.jpegx_stream_synchronize(stream), "sync")
+
+    flags = jpegx.F_PIXEL_INPUT
+
+    def step():
+        jpegx.forward_fused_device(in_ptr, H, W, out_ptr, args.mode, args.param, flags, stream=stream)
+
+    def barrier():
+        jpegx.check(L.jpegx_device_synchronize(), "sync")
+        if dist is not None:
+            dist.barrier()
+            jpegx.check(L.jpegx_device_synchronize(), "sync")
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ev0, ev1 = jpegx.Event(), jpegx.Event()
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    for _ in range(args.steps):
+        step()
+    ev1.record(stream)
+    jpegx.check(L.jpegx_device_synchronize(), "sync")
+    t_local = time.perf_counter() - t0
+    kernel_ms = ev0.elapsed_ms(ev1) / args.steps     # average launch duration on the launch stream
+    barrier()
+
+    t_max = t_local
+    if dist is not None:
+        tt = torch.tensor([t_local], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        t_max = float(tt.item())
+    total_blocks = blocks_per_step * args.steps * world
+    value = total_blocks / t_max / 1e6
+
+    # --- exact-tier census (untimed): how many blocks took the float64 path -----------------------
+    cnt = jpegx.DeviceBuffer(16)
+    jpegx.check(L.jpegx_memset(cnt.ptr, 0, 16, stream), "memset")
+    jpegx.check(L.jpegx_set_debug_counters(cnt.ptr), "counters")
+    step()
+    jpegx.check(L.jpegx_device_synchronize(), "sync")
+    jpegx.check(L.jpegx_set_debug_counters(None), "counters")
+    census = cnt.download((2,), np.uint64)
+    exact_frac = float(census[0]) / max(1.0, float(census[1]))
+
+    # --- verification against the oracle (untimed, rank-local first plane) ------------------------
+    verified = None
+    if not args.no_verify:
+        import oracle
+        from jpegx import synth
+        vh = min(size, 1024)
+        want = oracle.forward_f32(synth.generate_plane(args.kind, vh, size, seed=0, plane=rank * planes),
+                                  args.mode, args.param)
+        if torch is not None:
+            got = t_out[: vh * size].cpu().numpy().reshape(vh // 8, size // 8, 64)
+        else:
+            got = b_out.download((vh // 8, size // 8, 64), np.int16)
+        verified = bool(np.array_equal(got, want))
+
+    # --- RCCL gather of the coefficient stream to rank 0 (separately timed) -----------------------
+    gather = None
+    if dist is not None and not args.no_gather:
+        gl = [torch.empty_like(t_out) for _ in range(world)] if rank == 0 else None
+        dist.gather(t_out, gl, dst=0)                      # warm-up / connection setup
+        torch.cuda.synchronize()
+        dist.barrier()
+        tg = time.perf_counter()
+        dist.gather(t_out, gl, dst=0)
+        torch.cuda.synchronize()
+        dist.barrier()
+        tg = time.perf_counter() - tg
+        tgt = torch.tensor([tg], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tgt, op=dist.ReduceOp.MAX)
+        tg = float(tgt.item())
+        ok = True
+        if rank == 0:
+            ok = bool(torch.equal(gl[0], t_out))
+        gather = {"ms": round(tg * 1e3, 3), "bytes_into_root": out_bytes * (world - 1),
+                  "GBps_into_root": round(out_bytes * (world - 1) / tg / 1e9, 2),
+                  "xgmi_bound_GBps": 7 * 153, "root_copy_ok": ok,
+                  "note": "ncclGather-style torch.distributed.gather of every rank's int16 stream; "
+                          "not part of `value` (compute phase), see DESIGN.md multi-GPU"}
+
+    achieved = BYTES_PER_BLOCK * blocks_per_step / (kernel_ms * 1e-3) / 1e9
+    result = {
+        "metric": "M 8x8 blocks/sec (DCT+quant+zigzag fused forward)",
+        "value": round(value, 2), "unit": "Mblocks/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(t_max / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic (%s planes generated on device, integer-valued 0..255)" % args.kind,
+        "config": {"workload": "configs[1]: %dx%d synthetic Y planes, 8x8 DCT + %s quantiser + zigzag, "
+                               "fp32 in / int16 out; %d distinct planes per step and GPU (one launch)"
+                               % (size, size, args.mode, planes),
+                   "planes_per_step_per_gpu": planes, "blocks_per_step_per_gpu": blocks_per_step,
+                   "parallelism": "planes sharded per GPU, no data-path collective in the timed region"},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                     "kernel": "k_forward_fused", "kernel_ms": round(kernel_ms, 4),
+                     "algorithmic_bytes_per_launch": BYTES_PER_BLOCK * blocks_per_step},
+        "exact_tier_block_fraction": round(exact_frac, 5),
+        "verified_vs_oracle": verified,
+        "device": jpegx.device_name(local_rank if world > 1 else 0),
+    }
+    if gather is not None:
+        result["gather"] = gather
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(size, args.kind)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,201 @@
+// jpegx_math.h -- per-block arithmetic shared by every kernel in jpegx_kernels.hip.
+//
+// Everything here is a plain inline function on registers so that tests/emul can compile
+// the very same arithmetic for the host (g++ -mfma -ffp-contract=off) and check it against
+// the oracle without a GPU.  Translation units including this file MUST be built with
+// -ffp-contract=off: every fused multiply-add is an explicit fma()/fmaf() call.
+//
+// Reference behaviour implemented (citations relative to /root/reference):
+//   transforms.py:4-11     un-normalised DCT-II matrix C[k][n] = cos(pi/8 (n+1/2) k)
+//   transforms.py:36-58    transform_1d / transform_2d           (forward, rows then columns)
+//   transforms.py:40-44,60-69  transform_1d_inverse / transform_2d_inverse (columns, rows)
+//   quantizers.py:4-53     the four quantisers, np.round == round-half-to-even
+//
+// Two arithmetic tiers:
+//   * fp32 fast tier: an even/odd factorisation of the 8-point DCT (35 flops per 1-D
+//     transform instead of 64).  It is NOT in the reference's summation order; it only has
+//     to land on the same integer after rounding, which is guaranteed by the error bound
+//     jpegx_fwd_err_bound()/jpegx_inv_err_bound(): whenever the fp32 value lies within the
+//     bound of a rounding boundary the coefficient is recomputed by
+//   * fp64 exact tier: the reference's own operation order (the OpenBLAS dgemv orders
+//     measured in the build container, see oracle/jpegx_oracle.c header), bit-identical to
+//     the float64 value NumPy produces, then rounded half-to-even like np.round.
+#pragma once
+#include <stdint.h>
+#include <math.h>
+
+#if defined(__HIPCC__) || defined(__CUDACC__)
+#define JPEGX_HD __host__ __device__ __forceinline__
+#else
+#define JPEGX_HD static inline __attribute__((always_inline))
+#endif
+
+#include "../../include/jpegx_tables.inc"
+
+// cos(m*pi/16) for the fast tier (fp32 roundings of the exact values)
+#define JPEGX_A1 0.98078528040323044913f
+#define JPEGX_A2 0.92387953251128675613f
+#define JPEGX_A3 0.83146961230254523708f
+#define JPEGX_A4 0.70710678118654752440f
+#define JPEGX_A5 0.55557023301960222474f
+#define JPEGX_A6 0.38268343236508977173f
+#define JPEGX_A7 0.19509032201612826785f
+
+// ---------------------------------------------------------------------------------------------
+// fp32 fast tier
+// ---------------------------------------------------------------------------------------------
+
+// y = C . x for one 8-vector, in place (transforms.py:36-38, different summation order).
+JPEGX_HD void jpegx_dct8_f32(float &x0, float &x1, float &x2, float &x3,
+                             float &x4, float &x5, float &x6, float &x7)
+{
+    const float s0 = x0 + x7, s1 = x1 + x6, s2 = x2 + x5, s3 = x3 + x4;
+    const float d0 = x0 - x7, d1 = x1 - x6, d2 = x2 - x5, d3 = x3 - x4;
+    const float e0 = s0 + s3, e1 = s1 + s2, e2 = s0 - s3, e3 = s1 - s2;
+    x0 = e0 + e1;
+    x4 = (e0 - e1) * JPEGX_A4;
+    x2 = fmaf(e3, JPEGX_A6, e2 * JPEGX_A2);
+    x6 = fmaf(e3, -JPEGX_A2, e2 * JPEGX_A6);
+    x1 = fmaf(d3, JPEGX_A7, fmaf(d2, JPEGX_A5, fmaf(d1, JPEGX_A3, d0 * JPEGX_A1)));
+    x3 = fmaf(d3, -JPEGX_A5, fmaf(d2, -JPEGX_A1, fmaf(d1, -JPEGX_A7, d0 * JPEGX_A3)));
+    x5 = fmaf(d3, JPEGX_A3, fmaf(d2, JPEGX_A7, fmaf(d1, -JPEGX_A1, d0 * JPEGX_A5)));
+    x7 = fmaf(d3, -JPEGX_A1, fmaf(d2, JPEGX_A3, fmaf(d1, -JPEGX_A5, d0 * JPEGX_A7)));
+}
+
+// x = Cn^T . (Dinv . X) = X0/8 + 1/4 sum_{k>=1} C[k][n] X[k], in place (transforms.py:40-44).
+JPEGX_HD void jpegx_idct8_f32(float &x0, float &x1, float &x2, float &x3,
+                              float &x4, float &x5, float &x6, float &x7)
+{
+    const float q = 0.25f;
+    const float p0 = x0 * 0.125f, p4 = x4 * (q * JPEGX_A4);
+    const float g0 = p0 + p4, g1 = p0 - p4;
+    const float h0 = fmaf(x6, q * JPEGX_A6, x2 * (q * JPEGX_A2));
+    const float h1 = fmaf(x6, -q * JPEGX_A2, x2 * (q * JPEGX_A6));
+    const float E0 = g0 + h0, E1 = g1 + h1, E2 = g1 - h1, E3 = g0 - h0;
+    const float O0 = fmaf(x7, q * JPEGX_A7, fmaf(x5, q * JPEGX_A5, fmaf(x3, q * JPEGX_A3, x1 * (q * JPEGX_A1))));
+    const float O1 = fmaf(x7, -q * JPEGX_A5, fmaf(x5, -q * JPEGX_A1, fmaf(x3, -q * JPEGX_A7, x1 * (q * JPEGX_A3))));
+    const float O2 = fmaf(x7, q * JPEGX_A3, fmaf(x5, q * JPEGX_A7, fmaf(x3, -q * JPEGX_A1, x1 * (q * JPEGX_A5))));
+    const float O3 = fmaf(x7, -q * JPEGX_A1, fmaf(x5, q * JPEGX_A3, fmaf(x3, -q * JPEGX_A5, x1 * (q * JPEGX_A7))));
+    x0 = E0 + O0; x7 = E0 - O0;
+    x1 = E1 + O1; x6 = E1 - O1;
+    x2 = E2 + O2; x5 = E2 - O2;
+    x3 = E3 + O3; x4 = E3 - O3;
+}
+
+// 2-D forward on a block held as v[row*8+col]: rows first, then columns (transforms.py:46-58).
+JPEGX_HD void jpegx_dct8x8_f32(float (&v)[64])
+{
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        jpegx_dct8_f32(v[i * 8 + 0], v[i * 8 + 1], v[i * 8 + 2], v[i * 8 + 3],
+                       v[i * 8 + 4], v[i * 8 + 5], v[i * 8 + 6], v[i * 8 + 7]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        jpegx_dct8_f32(v[0 * 8 + j], v[1 * 8 + j], v[2 * 8 + j], v[3 * 8 + j],
+                       v[4 * 8 + j], v[5 * 8 + j], v[6 * 8 + j], v[7 * 8 + j]);
+}
+
+// 2-D inverse: columns first, then rows (transforms.py:60-69).
+JPEGX_HD void jpegx_idct8x8_f32(float (&v)[64])
+{
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        jpegx_idct8_f32(v[0 * 8 + j], v[1 * 8 + j], v[2 * 8 + j], v[3 * 8 + j],
+                        v[4 * 8 + j], v[5 * 8 + j], v[6 * 8 + j], v[7 * 8 + j]);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        jpegx_idct8_f32(v[i * 8 + 0], v[i * 8 + 1], v[i * 8 + 2], v[i * 8 + 3],
+                        v[i * 8 + 4], v[i * 8 + 5], v[i * 8 + 6], v[i * 8 + 7]);
+}
+
+// Rigorous bound on |fp32 fast-tier coefficient - float64 reference coefficient| for a block
+// whose samples have absolute sum S (any fp32 inputs).  Derivation in DESIGN.md ("error
+// bound"): every intermediate of either pass is bounded by the running absolute sums, each
+// 1-D output sees at most 6 roundings on its dependency chain (1 butterfly add, <=4 fma/mul,
+// constants rounded to fp32), the second pass amplifies first-pass errors by at most
+// sum|C[k][i]| <= 8 -- first order 12 u S with u = 2^-24; quantisation adds <= 2 u S (fp32
+// reciprocal and product).  16 u S = 2^-20 S leaves a margin for second-order terms.
+JPEGX_HD float jpegx_fwd_err_bound(float S) { return S * 0x1p-20f; }
+
+// Same for the inverse: |output error| <= 12 u * (1/4) * sum|Z| (<= 2^-22 * sum|Z| with margin).
+JPEGX_HD float jpegx_inv_err_bound(float S) { return S * 0x1p-22f; }
+
+// ---------------------------------------------------------------------------------------------
+// fp64 exact tier (reference operation order)
+// ---------------------------------------------------------------------------------------------
+
+// C[k] . x with x strided: a_n = c_n x_n (n<4); a_n = fma(c_{n+4}, x_{n+4}, a_n); (a0+a2)+(a1+a3)
+JPEGX_HD double jpegx_dot8_ref(const double *c, const double *x, int sx)
+{
+    double a0 = c[0] * x[0 * sx];
+    double a1 = c[1] * x[1 * sx];
+    double a2 = c[2] * x[2 * sx];
+    double a3 = c[3] * x[3 * sx];
+    a0 = fma(c[4], x[4 * sx], a0);
+    a1 = fma(c[5], x[5 * sx], a1);
+    a2 = fma(c[6], x[6 * sx], a2);
+    a3 = fma(c[7], x[7 * sx], a3);
+    return (a0 + a2) + (a1 + a3);
+}
+
+// Output sample i of Cn^T . u where u = Dinv * X already applied; cn_col[j] = Cn[j][i].
+// p = w1 u1; p = fma(w0,u0,p); fma(w2,u2,p); fma(w3,u3,p); q likewise over 5,4,6,7; p + q.
+JPEGX_HD double jpegx_idot8_ref(const double *w, const double *u, int su)
+{
+    double p = w[1] * u[1 * su];
+    p = fma(w[0], u[0 * su], p);
+    p = fma(w[2], u[2 * su], p);
+    p = fma(w[3], u[3 * su], p);
+    double q = w[5] * u[5 * su];
+    q = fma(w[4], u[4 * su], q);
+    q = fma(w[6], u[6 * su], q);
+    q = fma(w[7], u[7 * su], q);
+    return p + q;
+}
+
+// quantiser modes; numbering is part of the C ABI (include/jpegx.h)
+enum { JPEGX_QM_NONE = 0, JPEGX_QM_DISCARD = 1, JPEGX_QM_DIVIDE = 2, JPEGX_QM_QTABLE = 3 };
+
+// quantizers.py:4-49 on one float64 coefficient at block position n = i*8+j.
+// rq64 = 1.0/q (correctly rounded IEEE division, what NumPy computes at quantizers.py:49).
+JPEGX_HD double jpegx_quant_ref(double a, int n, int mode, double param, const double *rq64)
+{
+    if (mode == JPEGX_QM_QTABLE) return rint(a * rq64[n]);
+    if (mode == JPEGX_QM_DIVIDE) return rint(a / param);
+    if (mode == JPEGX_QM_DISCARD) {
+        const int keep = (int)param;
+        return ((n >> 3) >= keep || (n & 7) >= keep) ? 0.0 : rint(a);
+    }
+    return rint(a);
+}
+
+// quantizers.py:8-9,30-31,51-53 (restore)
+JPEGX_HD double jpegx_restore_ref(double a, int n, int mode, double param, const int *qt)
+{
+    if (mode == JPEGX_QM_QTABLE) return rint(a * (double)qt[n]);
+    if (mode == JPEGX_QM_DIVIDE) return a * param;
+    return a;
+}
+
+JPEGX_HD int jpegx_clamp_i16(double r)
+{
+    return r > 32767.0 ? 32767 : (r < -32768.0 ? -32768 : (int)r);
+}
+
+// ---------------------------------------------------------------------------------------------
+// synthetic planes (jpegx/synth.py is the host twin)
+// ---------------------------------------------------------------------------------------------
+JPEGX_HD uint32_t jpegx_hash32(uint32_t x)
+{
+    x ^= x >> 16; x *= 0x7FEB352Du;
+    x ^= x >> 15; x *= 0x846CA68Bu;
+    x ^= x >> 16;
+    return x;
+}
+
+JPEGX_HD uint32_t jpegx_synth_pixel(int kind, uint32_t pseed, uint32_t width, uint32_t y, uint32_t x)
+{
+    const uint32_t h = jpegx_hash32((y * width + x) ^ pseed);
+    if (kind == 0) return h >> 24;
+    return (((3u * x + 5u * y) >> 4) & 127u) + 64u * (((x >> 6) ^ (y >> 6)) & 1u) + (h & 15u);
+}

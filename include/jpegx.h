@@ -1,0 +1,169 @@
+/*
+ * jpegx.h -- C ABI of libjpegx.so: the MI355X (gfx950) implementation of the per-8x8-block
+ * transform path of X-rayLaser/Implementing-JPEG-compression (steps 4-6 of its pipeline and
+ * their inverses).
+ *
+ * Boundary contract:
+ *   - extern "C", plain pointers and sizes only; every function returns 0 on success or a
+ *     negative JPEGX_E_* code, and jpegx_last_error() returns a thread-local message.
+ *   - The caller owns host buffers; device buffers are plain device pointers (from
+ *     jpegx_malloc, hipMalloc or torch .data_ptr() -- they are interchangeable).
+ *   - Every compute entry takes a stream handle (hipStream_t cast to void*; NULL = the
+ *     default stream) and only ENQUEUES work: no allocation, no synchronisation, so calls
+ *     can be captured into a hipGraph.  jpegx_host_* variants are the synchronous
+ *     host-pointer conveniences used by the Python step classes.
+ *   - One host thread per device is safe; the library keeps no mutable global state besides
+ *     the thread-local error string and the current HIP device of the calling thread.
+ *
+ * The reference has no native boundary (it is pure Python); each entry point below names the
+ * reference function(s) whose work it replaces, relative to /root/reference.
+ *
+ * Plane layout: row-major, `pitch` in ELEMENTS between rows, H and W multiples of 8.
+ * Coefficient stream layout ("zigzag stream"): int16 [H/8][W/8][64], block-row-major, the 64
+ * coefficients of a block contiguous in zigzag order -- pipeline/zigzag_order.py:85-99.
+ */
+#ifndef JPEGX_H
+#define JPEGX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define JPEGX_VERSION 100 /* major*10000 + minor*100 + patch */
+
+/* error codes */
+#define JPEGX_OK 0
+#define JPEGX_E_INVALID (-1)  /* bad argument (shape not a multiple of 8, null pointer, bad mode ...) */
+#define JPEGX_E_HIP (-2)      /* a HIP runtime call failed; message has hipGetErrorString */
+#define JPEGX_E_NODEVICE (-3) /* no usable GPU */
+#define JPEGX_E_UNSUPPORTED (-4)
+
+/* Quantiser selection: pipeline/__init__.py:13-19 (QuantizationMethod.name_to_quantizer). */
+typedef enum jpegx_quant_mode {
+    JPEGX_Q_NONE = 0,    /* RoundingQuantizer        quantizers.py:4-9    round(a)                 */
+    JPEGX_Q_DISCARD = 1, /* DiscardingQuantizer      quantizers.py:12-20  param = keep             */
+    JPEGX_Q_DIVIDE = 2,  /* DivisionQuantizer        quantizers.py:23-31  param = divisor          */
+    JPEGX_Q_QTABLE = 3   /* JpegQuantizationTable    quantizers.py:34-53  fixed luminance table    */
+} jpegx_quant_mode;
+
+/* flags for the fused kernels */
+#define JPEGX_F_PIXEL_INPUT 1u /* forward: every sample is a non-negative multiple of 2^-8 below 2^9  \
+                                  (8-bit pixels, or their 2x2/4x4 means), so partial sums are exact   \
+                                  in fp32; lets the kernel use DC as the error-bound scale            */
+#define JPEGX_F_CLAMP_U8 2u    /* inverse: fuse the clamp to [0,255] of pipeline/normalization.py:10-14 */
+
+/* output element type of jpegx_inverse_fused */
+typedef enum jpegx_out_type {
+    JPEGX_OUT_F32 = 0, /* float samples (integers after np.round, basis_change.py:43) */
+    JPEGX_OUT_I16 = 1, /* int16 */
+    JPEGX_OUT_U8 = 2   /* uint8, implies clamping */
+} jpegx_out_type;
+
+typedef void *jpegx_stream_t; /* hipStream_t */
+typedef void *jpegx_event_t;  /* hipEvent_t  */
+
+/* ---- library / device management ------------------------------------------------------- */
+const char *jpegx_last_error(void);
+int jpegx_version(void);
+int jpegx_device_count(int *count);
+int jpegx_set_device(int device);
+int jpegx_get_device(int *device);
+int jpegx_device_name(int device, char *buf, size_t buflen);
+int jpegx_device_synchronize(void);
+
+int jpegx_malloc(void **dptr, size_t bytes);
+int jpegx_free(void *dptr);
+int jpegx_memset(void *dptr, int value, size_t bytes, jpegx_stream_t stream);
+int jpegx_memcpy_h2d(void *dst, const void *src, size_t bytes, jpegx_stream_t stream);
+int jpegx_memcpy_d2h(void *dst, const void *src, size_t bytes, jpegx_stream_t stream);
+int jpegx_memcpy_d2d(void *dst, const void *src, size_t bytes, jpegx_stream_t stream);
+
+int jpegx_stream_create(jpegx_stream_t *stream);
+int jpegx_stream_destroy(jpegx_stream_t stream);
+int jpegx_stream_synchronize(jpegx_stream_t stream);
+int jpegx_event_create(jpegx_event_t *event);
+int jpegx_event_destroy(jpegx_event_t event);
+int jpegx_event_record(jpegx_event_t event, jpegx_stream_t stream);
+int jpegx_event_synchronize(jpegx_event_t event);
+int jpegx_event_elapsed_ms(jpegx_event_t start, jpegx_event_t stop, float *ms);
+
+/* ---- synthetic planes (no reference counterpart; stands in for util.band_to_array,
+ *      util.py:110-112).  Writes rows row0..row0+H-1 of plane `plane` of the integer-only
+ *      generator documented in jpegx/synth.py: kind 0 = uniform noise 0..255, 1 = smooth. --- */
+int jpegx_generate_plane(float *d_plane, int H, int W, ptrdiff_t pitch, int kind, uint32_t seed,
+                         uint32_t plane, int row0, jpegx_stream_t stream);
+
+/* ---- the hot path, fused ------------------------------------------------------------------
+ * Forward: replaces BasisChange.execute (pipeline/basis_change.py:11-18) + Quantization.execute
+ * (pipeline/quantization.py:8-18) + ZigzagOrder.execute (pipeline/zigzag_order.py:85-99) for
+ * transform='DCT', dct_size=8.  d_in: fp32 plane [H][pitch]; d_out: int16 zigzag stream.
+ * Output integers are bit-exact with the float64 reference (values saturate to int16).      */
+int jpegx_forward_fused(const float *d_in, int H, int W, ptrdiff_t pitch, int mode, double param,
+                        unsigned flags, int16_t *d_out, jpegx_stream_t stream);
+
+/* Same with the SubSampling mean-pool prologue fused (pipeline/subsampling.py:9-11): the
+ * input plane is [H*bs][W*bs] and is averaged over bs x bs tiles (bs in {1,2,4}) on load.    */
+int jpegx_forward_fused_pooled(const float *d_in, int H, int W, ptrdiff_t pitch, int bs, int mode,
+                               double param, unsigned flags, int16_t *d_out, jpegx_stream_t stream);
+
+/* Inverse: replaces ZigzagOrder.invert (zigzag_order.py:101-119) + Quantization.invert
+ * (quantization.py:20-30) + BasisChange.invert (basis_change.py:28-43, including its final
+ * np.round).  d_in: int16 zigzag stream; d_out: [H][out_pitch] of out_type.                  */
+int jpegx_inverse_fused(const int16_t *d_in, int H, int W, int mode, double param, unsigned flags,
+                        void *d_out, ptrdiff_t out_pitch, int out_type, jpegx_stream_t stream);
+
+/* ---- unfused fp32 stage kernels (per-stage parity; coefficients within 1e-4 of the float64
+ *      reference, normalised by the block maximum) ---------------------------------------- */
+/* DCT.transform_2d blockwise: transforms.py:46-58 via basis_change.py:15-18 */
+int jpegx_dct8x8_f32(const float *d_in, int H, int W, ptrdiff_t pitch, float *d_out,
+                     ptrdiff_t out_pitch, jpegx_stream_t stream);
+/* DCT.transform_2d_inverse blockwise (no rounding): transforms.py:60-69 */
+int jpegx_idct8x8_f32(const float *d_in, int H, int W, ptrdiff_t pitch, float *d_out,
+                      ptrdiff_t out_pitch, jpegx_stream_t stream);
+
+/* ---- exact float64 stage kernels: bit-identical to the reference's float64 arrays; these
+ *      back the stand-alone step classes (BasisChange / Quantization / ZigzagOrder) -------- */
+/* BasisChange.execute, DCT branch: basis_change.py:15-18 */
+int jpegx_dct8x8_f64(const double *d_in, int H, int W, ptrdiff_t pitch, double *d_out,
+                     ptrdiff_t out_pitch, jpegx_stream_t stream);
+/* BasisChange.invert, DCT branch: basis_change.py:33-35 (+ np.round of :43 when do_round) */
+int jpegx_idct8x8_f64(const double *d_in, int H, int W, ptrdiff_t pitch, double *d_out,
+                      ptrdiff_t out_pitch, int do_round, jpegx_stream_t stream);
+/* Quantization.execute / invert: quantization.py:8-30 with quantizers.py:4-53 */
+int jpegx_quantize_f64(const double *d_in, int H, int W, ptrdiff_t pitch, int mode, double param,
+                       double *d_out, ptrdiff_t out_pitch, jpegx_stream_t stream);
+int jpegx_restore_f64(const double *d_in, int H, int W, ptrdiff_t pitch, int mode, double param,
+                      double *d_out, ptrdiff_t out_pitch, jpegx_stream_t stream);
+/* ZigzagOrder.execute / invert: zigzag_order.py:85-119; elem_size in {2,4,8,16} bytes */
+int jpegx_zigzag(const void *d_in, int H, int W, ptrdiff_t pitch, int elem_size, void *d_out,
+                 jpegx_stream_t stream);
+int jpegx_unzigzag(const void *d_in, int H, int W, int elem_size, void *d_out, ptrdiff_t out_pitch,
+                   jpegx_stream_t stream);
+
+/* ---- synchronous host-pointer conveniences (H2D, kernel, D2H on an internal stream) ------ */
+int jpegx_host_forward_fused(const float *h_in, int H, int W, ptrdiff_t pitch, int mode,
+                             double param, unsigned flags, int16_t *h_out);
+int jpegx_host_inverse_fused(const int16_t *h_in, int H, int W, int mode, double param,
+                             unsigned flags, void *h_out, ptrdiff_t out_pitch, int out_type);
+int jpegx_host_dct8x8_f64(const double *h_in, int H, int W, double *h_out);
+int jpegx_host_idct8x8_f64(const double *h_in, int H, int W, double *h_out, int do_round);
+int jpegx_host_quantize_f64(const double *h_in, int H, int W, int mode, double param, double *h_out);
+int jpegx_host_restore_f64(const double *h_in, int H, int W, int mode, double param, double *h_out);
+int jpegx_host_zigzag(const void *h_in, int H, int W, int elem_size, void *h_out);
+int jpegx_host_unzigzag(const void *h_in, int H, int W, int elem_size, void *h_out);
+int jpegx_host_dct8x8_f32(const float *h_in, int H, int W, float *h_out);
+int jpegx_host_idct8x8_f32(const float *h_in, int H, int W, float *h_out);
+
+/* ---- instrumentation ---------------------------------------------------------------------
+ * When d_counters is non-NULL the fused kernels atomically add, per launch:
+ * [0] blocks that took the float64 exact tier, [1] blocks processed.  Pass NULL (default) in
+ * production.  Set with jpegx_set_debug_counters for the calling thread.                     */
+int jpegx_set_debug_counters(unsigned long long *d_counters);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JPEGX_H */

@@ -1,0 +1,166 @@
+"""GPU parity (MI355X): every kernel of libjpegx.so, through the C ABI, against the oracle and
+against the golden vectors produced by the unmodified reference (tests/golden/make_golden.py)."""
+import numpy as np
+import pytest
+
+import oracle
+from conftest import CASES, MODES
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("suffix,mode,param", MODES)
+def test_forward_fused_matches_reference_golden(gpu, golden, case, suffix, mode, param):
+    """Steps 4+5+6 fused: quantised + zigzagged integers bit-exact vs the reference's output."""
+    c = golden(case)
+    pre = c["pre"].astype(np.float32)
+    assert np.array_equal(pre.astype(np.float64), c["pre"])  # inputs are exact in fp32
+    got = gpu.forward_fused(pre, mode, param)
+    assert got.dtype == np.int16 and got.shape == c["zz_" + suffix].shape
+    assert np.array_equal(got, c["zz_" + suffix])
+    # the generic (no pixel promise) variant must agree too
+    got2 = gpu.forward_fused(pre, mode, param, pixel_input=False)
+    assert np.array_equal(got2, c["zz_" + suffix])
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("suffix,mode,param", MODES)
+def test_inverse_fused_matches_reference_golden(gpu, golden, case, suffix, mode, param):
+    """Steps 6+5+4 inverted, fused: rounded samples bit-exact vs BasisChange.invert of the reference."""
+    c = golden(case)
+    zz = c["zz_" + suffix]
+    want = c["idct_" + suffix]
+    got = gpu.inverse_fused(zz, mode, param, out="f32")
+    assert np.array_equal(got.astype(np.int64), want)
+    got16 = gpu.inverse_fused(zz, mode, param, out="i16")
+    assert np.array_equal(got16.astype(np.int64), want)
+    gotu8 = gpu.inverse_fused(zz, mode, param, out="u8")
+    assert np.array_equal(gotu8.astype(np.int64), np.clip(want, 0, 255))
+    gotc = gpu.inverse_fused(zz, mode, param, out="f32", clamp=True)
+    assert np.array_equal(gotc.astype(np.int64), np.clip(want, 0, 255))
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_exact_f64_stage_kernels_bit_identical(gpu, golden, case):
+    """The float64 stage kernels reproduce the reference's float64 arrays bit for bit."""
+    c = golden(case)
+    dct = gpu.dct8x8_f64(c["pre"])
+    assert np.array_equal(dct, c["dct"])
+    for suffix, mode, param in MODES:
+        q = gpu.quantize_f64(dct, mode, param)
+        assert np.array_equal(q, c["q_" + suffix].astype(np.float64))
+        z = gpu.zigzag(q)
+        assert np.array_equal(z, c["zz_" + suffix].astype(np.float64))
+        back = gpu.unzigzag(z)
+        assert np.array_equal(back, q)
+        r = gpu.restore_f64(back, mode, param)
+        assert np.array_equal(r, c["restore_" + suffix].astype(np.float64))
+        i = gpu.idct8x8_f64(r, do_round=True)
+        assert np.array_equal(i, c["idct_" + suffix].astype(np.float64))
+        fl = gpu.idct8x8_f64(r, do_round=False)
+        assert np.array_equal(fl, oracle.idct_plane(r, rounded=False))
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_dct_f32_within_1e4_of_reference(gpu, golden, case):
+    """Unfused fp32 DCT: |c_gpu - c_ref| <= 1e-4 * max(1, max_block |c_ref|) (north_star tolerance)."""
+    c = golden(case)
+    ref = c["dct"]
+    got = gpu.dct8x8_f32(c["pre"].astype(np.float32)).astype(np.float64)
+    h, w = ref.shape
+    blockmax = np.abs(ref).reshape(h // 8, 8, w // 8, 8).max(axis=(1, 3))
+    tol = 1e-4 * np.maximum(1.0, blockmax)
+    err = np.abs(got - ref).reshape(h // 8, 8, w // 8, 8).max(axis=(1, 3))
+    assert np.all(err <= tol), float((err / tol).max())
+    # and the fp32 inverse brings the coefficients back to the samples
+    back = gpu.idct8x8_f32(got.astype(np.float32))
+    assert np.allclose(back, c["pre"], atol=2e-3)
+
+
+def test_zigzag_element_sizes(gpu):
+    rng = np.random.default_rng(3)
+    for dt in (np.int16, np.float32, np.float64, np.complex128):
+        a = rng.integers(-1000, 1000, (16, 24)).astype(dt)
+        z = gpu.zigzag(a)
+        assert np.array_equal(z, oracle.zigzag_plane(a.real).astype(dt) if dt != np.complex128
+                              else oracle.zigzag_plane(a.real).astype(dt))
+        assert np.array_equal(gpu.unzigzag(z), a)
+
+
+@pytest.mark.parametrize("kind", ["noise", "smooth"])
+def test_generator_matches_host_twin(gpu, kind):
+    h, w = 64, 256
+    buf = gpu.DeviceBuffer(h * w * 4)
+    gpu.generate_plane_device(buf.ptr, h, w, kind, seed=5, plane=3, row0=16)
+    got = buf.download((h, w), np.float32)
+    want = gpu.synth.generate_plane(kind, h, w, seed=5, plane=3, row0=16)
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("kind,size", [("noise", 1024), ("smooth", 1024), ("noise", 4096)])
+@pytest.mark.parametrize("suffix,mode,param", MODES + [("divide7", "divide", 7.0)])
+def test_forward_fused_vs_oracle_large(gpu, kind, size, suffix, mode, param):
+    """Config-2-sized planes against the C oracle on identical synthetic input (bit-exact)."""
+    if size == 4096 and mode != "qtable":
+        pytest.skip("full-size plane is checked for the headline quantiser only")
+    a = gpu.synth.generate_plane(kind, size, size, seed=11)
+    got = gpu.forward_fused(a, mode, param)
+    want = oracle.forward_f32(a, mode, param)
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("kind", ["noise", "smooth"])
+@pytest.mark.parametrize("suffix,mode,param", MODES)
+def test_inverse_fused_vs_oracle_large(gpu, kind, suffix, mode, param):
+    a = gpu.synth.generate_plane(kind, 1024, 1024, seed=12)
+    zz = oracle.forward_f32(a, mode, param)
+    got = gpu.inverse_fused(zz, mode, param, out="i16")
+    want = oracle.inverse_i16(zz, mode, param)
+    assert np.array_equal(got.astype(np.int32), want)
+
+
+def test_pooled_forward_matches_reference_golden(gpu, golden):
+    """Fused 2x2 mean prologue (config 3 chroma path) == SubSampling + steps 4-6 of the reference."""
+    c = golden("pooled128")
+    raw = c["input"].astype(np.float32)
+    for suffix, mode, param in MODES:
+        got = gpu.forward_fused_pooled(raw, 2, mode, param)
+        assert np.array_equal(got, c["zz_" + suffix])
+    # 4x4 pooling against the oracle
+    a = gpu.synth.generate_plane("noise", 256, 256, seed=21)
+    pooled = oracle.mean_pool(a, 4)
+    got = gpu.forward_fused_pooled(a, 4, "qtable")
+    assert np.array_equal(got, oracle.forward_f32(pooled.astype(np.float32), "qtable"))
+
+
+def test_ragged_block_counts(gpu):
+    """Block counts that are not multiples of 64 exercise the partial last wave."""
+    for h, w in [(8, 8), (8, 40), (24, 72), (16, 520), (72, 8)]:
+        a = gpu.synth.generate_plane("noise", h, w, seed=h * 131 + w)
+        assert np.array_equal(gpu.forward_fused(a, "qtable"), oracle.forward_f32(a, "qtable"))
+        zz = oracle.forward_f32(a, "qtable")
+        assert np.array_equal(gpu.inverse_fused(zz, "qtable", out="i16").astype(np.int32), oracle.inverse_i16(zz, "qtable"))
+
+
+def test_round_trip_psnr(gpu):
+    """Config 4: forward then inverse on the GPU; PSNR vs input matches the oracle's round trip."""
+    a = gpu.synth.generate_plane("smooth", 1024, 1024, seed=4)
+    zz = gpu.forward_fused(a, "qtable")
+    rec = gpu.inverse_fused(zz, "qtable", out="u8").astype(np.float64)
+    mse = np.mean((rec - a) ** 2)
+    psnr = 10 * np.log10(255.0 ** 2 / mse)
+    ref = np.clip(oracle.inverse_i16(oracle.forward_f32(a, "qtable"), "qtable"), 0, 255)
+    psnr_ref = 10 * np.log10(255.0 ** 2 / np.mean((ref - a) ** 2))
+    assert abs(psnr - psnr_ref) < 1e-9
+    assert psnr > 30.0
+
+
+def test_bad_arguments_raise(gpu):
+    a = np.zeros((12, 16), dtype=np.float32)
+    with pytest.raises(gpu.JpegxError):
+        gpu.forward_fused(a, "qtable")          # height not a multiple of 8
+    with pytest.raises(gpu.JpegxError):
+        gpu.forward_fused(np.zeros((8, 8), np.float32), "divide", 0.0)
+    with pytest.raises(gpu.JpegxError):
+        gpu.forward_fused(np.zeros((8, 8), np.float32), "bogus")
