@@ -71,6 +71,35 @@ struct QuantParams {
 // both the per-lane row writes and the linear read-out are bank-conflict free.
 __device__ __forceinline__ int tile_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
 
+// 16-byte global accesses with a selectable cache policy.  NT = nontemporal ("nt" bit): the
+// planes and the coefficient stream are touched exactly once, so they should not displace
+// each other in L2/MALL; on MI355X a 2:1 read:write stream runs ~10 % faster with nt
+// (microbench/membench.hip: 5.7 -> 6.3 TB/s).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+template <bool NT> __device__ __forceinline__ f32x4 ld_f32x4(const float *p)
+{
+    return NT ? __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(p)) : *reinterpret_cast<const f32x4 *>(p);
+}
+template <bool NT> __device__ __forceinline__ u32x4 ld_u32x4(const void *p)
+{
+    return NT ? __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p)) : *reinterpret_cast<const u32x4 *>(p);
+}
+template <bool NT> __device__ __forceinline__ void st_u32x4(void *p, u32x4 v)
+{
+    if (NT) __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(p)); else *reinterpret_cast<u32x4 *>(p) = v;
+}
+template <bool NT> __device__ __forceinline__ void st_f32x4(float *p, f32x4 v)
+{
+    if (NT) __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(p)); else *reinterpret_cast<f32x4 *>(p) = v;
+}
+template <bool NT> __device__ __forceinline__ void st_u32x2(void *p, u32x2 v)
+{
+    if (NT) __builtin_nontemporal_store(v, reinterpret_cast<u32x2 *>(p)); else *reinterpret_cast<u32x2 *>(p) = v;
+}
+
 constexpr int TILE_BYTES = 64 * 128;
 constexpr int SCRATCH_DOUBLES = 128;  // sA[64] + sM[64]
 constexpr int LDS_BYTES = TILE_BYTES + SCRATCH_DOUBLES * 8;
@@ -118,7 +147,7 @@ __device__ __forceinline__ double coop_inv_exact(double z_own, double *sA, doubl
 // fused forward: DCT + quantise + zigzag.  VAR bit0 = PIXEL_INPUT, bit1 = DC exact.
 // BS = mean-pool factor of the fused SubSampling prologue (1 = none).
 // ------------------------------------------------------------------------------------------------
-template <int VAR, int BS>
+template <int VAR, int BS, bool NT>
 __global__ __launch_bounds__(64) void k_forward_fused(const float *__restrict__ in, size_t pitch, int wb,
                                                       int nblk, QuantParams prm, int16_t *__restrict__ out,
                                                       unsigned long long *counters)
@@ -141,8 +170,8 @@ __global__ __launch_bounds__(64) void k_forward_fused(const float *__restrict__ 
     if (BS == 1) {
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
-            const float4 *row = reinterpret_cast<const float4 *>(src + (size_t)r * pitch);
-            const float4 lo = row[0], hi = row[1];
+            const float *row = src + (size_t)r * pitch;
+            const f32x4 lo = ld_f32x4<NT>(row), hi = ld_f32x4<NT>(row + 4);
             v[r * 8 + 0] = lo.x; v[r * 8 + 1] = lo.y; v[r * 8 + 2] = lo.z; v[r * 8 + 3] = lo.w;
             v[r * 8 + 4] = hi.x; v[r * 8 + 5] = hi.y; v[r * 8 + 6] = hi.z; v[r * 8 + 7] = hi.w;
         }
@@ -156,10 +185,10 @@ __global__ __launch_bounds__(64) void k_forward_fused(const float *__restrict__ 
             for (int c = 0; c < 8; ++c) acc[c] = 0.f;
 #pragma unroll
             for (int a = 0; a < BS; ++a) {
-                const float4 *row = reinterpret_cast<const float4 *>(src + (size_t)(r * BS + a) * pitch);
+                const float *row = src + (size_t)(r * BS + a) * pitch;
 #pragma unroll
                 for (int q = 0; q < 2 * BS; ++q) {
-                    const float4 t = row[q];
+                    const f32x4 t = ld_f32x4<NT>(row + 4 * q);
                     const float e[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
                     for (int s = 0; s < 4; ++s) acc[(q * 4 + s) / BS] += e[s];
@@ -177,7 +206,8 @@ __global__ __launch_bounds__(64) void k_forward_fused(const float *__restrict__ 
     }
     jpegx_dct8x8_f32(v);
     if (PIXEL) S = v[0];  // non-negative samples: sum|x| == DC, exact
-    const float E = jpegx_fwd_err_bound(S);
+    // generic pooled input: the fp32 tile sums are themselves rounded (<= BS^2 u each)
+    const float E = jpegx_fwd_err_bound(S) * ((PIXEL || BS == 1) ? 1.0f : 1.0f + (BS * BS) / 16.0f);
 
     // quantise in zigzag order, pack pairs, track the worst rounding margin
     float worst = 0.f;
@@ -245,15 +275,154 @@ __global__ __launch_bounds__(64) void k_forward_fused(const float *__restrict__ 
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int row = i * 8 + (lane >> 3), c = lane & 7;
-        const uint4 q = *reinterpret_cast<const uint4 *>(lds + tile_off(row, c));
-        if (g0 + row < nblk) *reinterpret_cast<uint4 *>(dst + (size_t)row * 128 + c * 16) = q;
+        const u32x4 q = *reinterpret_cast<const u32x4 *>(lds + tile_off(row, c));
+        if (g0 + row < nblk) st_u32x4<NT>(dst + (size_t)row * 128 + c * 16, q);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// fused forward, LDS-staged input (the default kernel).  The wave's 64 blocks -- when W/8 is a
+// multiple of 64, one 8-row x 2 KiB strip of the plane -- are brought in by LDS-DMA
+// (global_load_lds_dwordx4: 16 pieces of 1 KiB, whole-128-B-line requests, no VGPR staging)
+// and each lane then picks its own block out of LDS.  Compared with per-lane global loads
+// (k_forward_fused: 16 B at a 32 B lane stride, every line touched by two instructions) this
+// reads each line exactly once, which is what lets the nontemporal policy pay off:
+// 5.6 -> 6.5 TB/s on MI355X (profiles/).  16-B chunks of a row are
+// stored at position c ^ f(c >> 1), f(b) = bit2(b) ^ bit3(b), which makes the per-lane
+// ds_read_b128 (lane stride 32 B) bank-conflict free; the permutation is applied on the DMA
+// SOURCE address because the DMA's LDS destination is always base + lane * 16.
+// After the compute the dead strip is reused as the output tile.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int strip_swz(int chunk) { return chunk ^ (((chunk >> 3) ^ (chunk >> 4)) & 1); }
+
+constexpr int STRIP_BYTES = 8 * 2048;
+constexpr int STRIP_LDS_BYTES = STRIP_BYTES + SCRATCH_DOUBLES * 8 + 128;
+
+template <int VAR, bool NT>
+__global__ __launch_bounds__(64) void k_forward_fused_strip(const float *__restrict__ in, size_t pitch, int wb,
+                                                            int nblk, QuantParams prm, int16_t *__restrict__ out,
+                                                            unsigned long long *counters)
+{
+    constexpr bool PIXEL = (VAR & 1) != 0;
+    constexpr bool DC_EXACT = (VAR & 2) != 0;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[STRIP_LDS_BYTES];
+    double *sA = reinterpret_cast<double *>(lds + STRIP_BYTES);
+    double *sM = sA + 64;
+    int16_t *sP = reinterpret_cast<int16_t *>(lds + STRIP_BYTES + SCRATCH_DOUBLES * 8);
+
+    const int lane = threadIdx.x;
+    const int g0 = blockIdx.x * 64;
+    const bool valid = g0 + lane < nblk;
+
+    // 16 DMA pieces of 1 KiB: piece (r, j) fills LDS bytes [r*2048 + j*1024, +1024); lane l of
+    // piece j fills chunk slot p = 64 j + l of the row, which holds chunk c = strip_swz(p) =
+    // half (c & 1) of block c >> 1.  Blocks past the end of the plane re-read the last block.
+    {
+        const float *src[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int c = strip_swz(64 * j + lane);
+            const int gb = min(g0 + (c >> 1), nblk - 1);
+            const int by = gb / wb, bx = gb - by * wb;
+            src[j] = in + (size_t)by * 8 * pitch + (size_t)bx * 8 + (c & 1) * 4;
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src[0] + (size_t)r * pitch),
+                                             (__attribute__((address_space(3))) void *)(lds + r * 2048), 16, 0, NT ? 2 : 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src[1] + (size_t)r * pitch),
+                                             (__attribute__((address_space(3))) void *)(lds + r * 2048 + 1024), 16, 0, NT ? 2 : 0);
+        }
+    }
+    __syncthreads();  // drains vmcnt: the strip has landed
+
+    float v[64];
+    {
+        const int f = ((lane >> 2) ^ (lane >> 3)) & 1;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const f32x4 lo = *reinterpret_cast<const f32x4 *>(lds + r * 2048 + ((2 * lane + f) << 4));
+            const f32x4 hi = *reinterpret_cast<const f32x4 *>(lds + r * 2048 + ((2 * lane + (f ^ 1)) << 4));
+            v[r * 8 + 0] = lo.x; v[r * 8 + 1] = lo.y; v[r * 8 + 2] = lo.z; v[r * 8 + 3] = lo.w;
+            v[r * 8 + 4] = hi.x; v[r * 8 + 5] = hi.y; v[r * 8 + 6] = hi.z; v[r * 8 + 7] = hi.w;
+        }
+    }
+
+    float S = 0.f;
+    if (!PIXEL) {
+#pragma unroll
+        for (int n = 0; n < 64; ++n) S += fabsf(v[n]);
+    }
+    jpegx_dct8x8_f32(v);
+    if (PIXEL) S = v[0];
+    const float E = jpegx_fwd_err_bound(S);
+
+    float worst = 0.f;
+    unsigned pk[32];
+#pragma unroll
+    for (int p = 0; p < 64; p += 2) {
+        int q[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int n = kZZ.v[p + h];
+            const float rq = prm.rq32[n];
+            const float t = v[n] * rq;
+            const float r = rintf(t);
+            if (!(DC_EXACT && n == 0)) worst = fmaxf(worst, fmaf(E, rq, fabsf(t - r)));
+            q[h] = (int)r;
+        }
+        if (PIXEL) {
+            pk[p >> 1] = ((unsigned)q[0] & 0xFFFFu) | ((unsigned)q[1] << 16);
+        } else {
+            const int a = min(max(q[0], -32768), 32767), b = min(max(q[1], -32768), 32767);
+            pk[p >> 1] = ((unsigned)a & 0xFFFFu) | ((unsigned)b << 16);
+        }
+    }
+
+    unsigned long long flagged = __ballot(valid && !(worst < 0.5f));
+    if (counters != nullptr && lane == 0) {
+        atomicAdd(&counters[0], (unsigned long long)__popcll(flagged));
+        atomicAdd(&counters[1], (unsigned long long)min(64, nblk - g0));
+    }
+    while (flagged) {   // exact tier, inputs re-read from the strip still resident in LDS
+        const int b = __ffsll((long long)flagged) - 1;
+        flagged &= flagged - 1;
+        const int i = lane >> 3, j = lane & 7;
+        const int fb = ((b >> 2) ^ (b >> 3)) & 1;
+        const float x = *reinterpret_cast<const float *>(lds + i * 2048 + ((2 * b + ((j >> 2) ^ fb)) << 4) + (j & 3) * 4);
+        const double y = coop_fwd_exact((double)x, sA, sM, lane);
+        const double r = jpegx_quant_ref(y, lane, prm.mode, prm.param, c_rq64.v);
+        sP[c_zzinv.v[lane]] = (int16_t)jpegx_clamp_i16(r);
+        __syncthreads();
+        if (lane == b) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const u32x4 t = *reinterpret_cast<const u32x4 *>(reinterpret_cast<unsigned char *>(sP) + c * 16);
+                pk[c * 4 + 0] = t.x; pk[c * 4 + 1] = t.y; pk[c * 4 + 2] = t.z; pk[c * 4 + 3] = t.w;
+            }
+        }
+        __syncthreads();
+    }
+
+    // the strip is dead: reuse its first 8 KiB as the swizzled output tile
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+        *reinterpret_cast<u32x4 *>(lds + tile_off(lane, c)) = u32x4{pk[c * 4 + 0], pk[c * 4 + 1], pk[c * 4 + 2], pk[c * 4 + 3]};
+    __syncthreads();
+    unsigned char *dst = reinterpret_cast<unsigned char *>(out) + (size_t)g0 * 128;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int row = i * 8 + (lane >> 3), c = lane & 7;
+        const u32x4 q = *reinterpret_cast<const u32x4 *>(lds + tile_off(row, c));
+        if (g0 + row < nblk) st_u32x4<NT>(dst + (size_t)row * 128 + c * 16, q);
     }
 }
 
 // ------------------------------------------------------------------------------------------------
 // fused inverse: un-zigzag + dequantise + IDCT + round (+ clamp).  OUT: 0 f32, 1 i16, 2 u8.
 // ------------------------------------------------------------------------------------------------
-template <int OUT>
+template <int OUT, bool NT>
 __global__ __launch_bounds__(64) void k_inverse_fused(const int16_t *__restrict__ in, int wb, int nblk,
                                                       QuantParams prm, int clamp, void *__restrict__ outv,
                                                       size_t opitch, unsigned long long *counters)
@@ -273,9 +442,9 @@ __global__ __launch_bounds__(64) void k_inverse_fused(const int16_t *__restrict_
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int row = i * 8 + (lane >> 3), c = lane & 7;
-        uint4 q = make_uint4(0, 0, 0, 0);
-        if (g0 + row < nblk) q = *reinterpret_cast<const uint4 *>(srcb + (size_t)row * 128 + c * 16);
-        *reinterpret_cast<uint4 *>(lds + tile_off(row, c)) = q;
+        u32x4 q = {0u, 0u, 0u, 0u};
+        if (g0 + row < nblk) q = ld_u32x4<NT>(srcb + (size_t)row * 128 + c * 16);
+        *reinterpret_cast<u32x4 *>(lds + tile_off(row, c)) = q;
     }
     __syncthreads();
 
@@ -341,9 +510,9 @@ __global__ __launch_bounds__(64) void k_inverse_fused(const int16_t *__restrict_
             float x[8];
 #pragma unroll
             for (int c = 0; c < 8; ++c) x[c] = clamp ? fminf(fmaxf(v[r * 8 + c], 0.f), 255.f) : v[r * 8 + c];
-            float4 *row = reinterpret_cast<float4 *>(o + (size_t)r * opitch);
-            row[0] = make_float4(x[0], x[1], x[2], x[3]);
-            row[1] = make_float4(x[4], x[5], x[6], x[7]);
+            float *row = o + (size_t)r * opitch;
+            st_f32x4<NT>(row, f32x4{x[0], x[1], x[2], x[3]});
+            st_f32x4<NT>(row + 4, f32x4{x[4], x[5], x[6], x[7]});
         }
     } else if (OUT == 1) {
         int16_t *o = reinterpret_cast<int16_t *>(outv) + (size_t)by * 8 * opitch + (size_t)bx * 8;
@@ -357,7 +526,7 @@ __global__ __launch_bounds__(64) void k_inverse_fused(const int16_t *__restrict_
                 const int a = min(max((int)lo, -32768), 32767), b2 = min(max((int)hi, -32768), 32767);
                 w[c] = ((unsigned)a & 0xFFFFu) | ((unsigned)b2 << 16);
             }
-            *reinterpret_cast<uint4 *>(o + (size_t)r * opitch) = make_uint4(w[0], w[1], w[2], w[3]);
+            st_u32x4<NT>(o + (size_t)r * opitch, u32x4{w[0], w[1], w[2], w[3]});
         }
     } else {
         unsigned char *o = reinterpret_cast<unsigned char *>(outv) + (size_t)by * 8 * opitch + (size_t)bx * 8;
@@ -369,7 +538,7 @@ __global__ __launch_bounds__(64) void k_inverse_fused(const int16_t *__restrict_
                 const unsigned u = (unsigned)fminf(fmaxf(v[r * 8 + c], 0.f), 255.f);
                 w[c >> 2] |= u << (8 * (c & 3));
             }
-            *reinterpret_cast<uint2 *>(o + (size_t)r * opitch) = make_uint2(w[0], w[1]);
+            st_u32x2<NT>(o + (size_t)r * opitch, u32x2{w[0], w[1]});
         }
     }
 }
@@ -561,7 +730,7 @@ int fill_inverse_params(int mode, double param, QuantParams *qp)
     }
 }
 
-template <int BS>
+template <int BS, bool NT>
 int launch_forward(const float *d_in, int H, int W, ptrdiff_t pitch, const QuantParams &qp, unsigned flags,
                    int16_t *d_out, hipStream_t st)
 {
@@ -571,12 +740,19 @@ int launch_forward(const float *d_in, int H, int W, ptrdiff_t pitch, const Quant
     // DC is an exact integer multiple of 2^-8 and rq[0] a power of two -> DC/q needs no tie check
     const bool dc_exact = pixel && is_pow2_float(qp.rq32[0]) &&
                           (qp.mode != JPEGX_Q_DIVIDE || (double)qp.rq32[0] * qp.param == 1.0);
-    if (dc_exact)
-        hipLaunchKernelGGL((k_forward_fused<3, BS>), grid, block, 0, st, d_in, (size_t)pitch, wb, nblk, qp, d_out, g_counters);
+    if (BS == 1 && !(flags & JPEGX_F_TUNE_NO_STRIP)) {
+        if (dc_exact)
+            hipLaunchKernelGGL((k_forward_fused_strip<3, NT>), grid, block, 0, st, d_in, (size_t)pitch, wb, nblk, qp, d_out, g_counters);
+        else if (pixel)
+            hipLaunchKernelGGL((k_forward_fused_strip<1, NT>), grid, block, 0, st, d_in, (size_t)pitch, wb, nblk, qp, d_out, g_counters);
+        else
+            hipLaunchKernelGGL((k_forward_fused_strip<0, NT>), grid, block, 0, st, d_in, (size_t)pitch, wb, nblk, qp, d_out, g_counters);
+    } else if (dc_exact)
+        hipLaunchKernelGGL((k_forward_fused<3, BS, NT>), grid, block, 0, st, d_in, (size_t)pitch, wb, nblk, qp, d_out, g_counters);
     else if (pixel)
-        hipLaunchKernelGGL((k_forward_fused<1, BS>), grid, block, 0, st, d_in, (size_t)pitch, wb, nblk, qp, d_out, g_counters);
+        hipLaunchKernelGGL((k_forward_fused<1, BS, NT>), grid, block, 0, st, d_in, (size_t)pitch, wb, nblk, qp, d_out, g_counters);
     else
-        hipLaunchKernelGGL((k_forward_fused<0, BS>), grid, block, 0, st, d_in, (size_t)pitch, wb, nblk, qp, d_out, g_counters);
+        hipLaunchKernelGGL((k_forward_fused<0, BS, NT>), grid, block, 0, st, d_in, (size_t)pitch, wb, nblk, qp, d_out, g_counters);
     HIP_TRY(hipGetLastError());
     return JPEGX_OK;
 }
@@ -760,9 +936,14 @@ int jpegx_forward_fused_pooled(const float *d_in, int H, int W, ptrdiff_t pitch,
     rc = fill_forward_params(mode, param, &qp);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
-    if (bs == 1) return launch_forward<1>(d_in, H, W, pitch, qp, flags, d_out, st);
-    if (bs == 2) return launch_forward<2>(d_in, H, W, pitch, qp, flags, d_out, st);
-    return launch_forward<4>(d_in, H, W, pitch, qp, flags, d_out, st);
+    if (flags & JPEGX_F_TUNE_NO_NT) {
+        if (bs == 1) return launch_forward<1, false>(d_in, H, W, pitch, qp, flags, d_out, st);
+        if (bs == 2) return launch_forward<2, false>(d_in, H, W, pitch, qp, flags, d_out, st);
+        return launch_forward<4, false>(d_in, H, W, pitch, qp, flags, d_out, st);
+    }
+    if (bs == 1) return launch_forward<1, true>(d_in, H, W, pitch, qp, flags, d_out, st);
+    if (bs == 2) return launch_forward<2, true>(d_in, H, W, pitch, qp, flags, d_out, st);
+    return launch_forward<4, true>(d_in, H, W, pitch, qp, flags, d_out, st);
 }
 
 int jpegx_forward_fused(const float *d_in, int H, int W, ptrdiff_t pitch, int mode, double param, unsigned flags,
@@ -787,12 +968,13 @@ int jpegx_inverse_fused(const int16_t *d_in, int H, int W, int mode, double para
     const dim3 grid((nblk + 63) / 64), block(64);
     const int clamp = (flags & JPEGX_F_CLAMP_U8) ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
-    if (out_type == JPEGX_OUT_F32)
-        hipLaunchKernelGGL((k_inverse_fused<0>), grid, block, 0, st, d_in, wb, nblk, qp, clamp, d_out, (size_t)out_pitch, g_counters);
-    else if (out_type == JPEGX_OUT_I16)
-        hipLaunchKernelGGL((k_inverse_fused<1>), grid, block, 0, st, d_in, wb, nblk, qp, clamp, d_out, (size_t)out_pitch, g_counters);
-    else
-        hipLaunchKernelGGL((k_inverse_fused<2>), grid, block, 0, st, d_in, wb, nblk, qp, 1, d_out, (size_t)out_pitch, g_counters);
+    const bool nt = (flags & JPEGX_F_TUNE_NO_NT) == 0;
+#define JPEGX_LAUNCH_INV(OUT, NT, CL) \
+    hipLaunchKernelGGL((k_inverse_fused<OUT, NT>), grid, block, 0, st, d_in, wb, nblk, qp, CL, d_out, (size_t)out_pitch, g_counters)
+    if (out_type == JPEGX_OUT_F32) { if (nt) JPEGX_LAUNCH_INV(0, true, clamp); else JPEGX_LAUNCH_INV(0, false, clamp); }
+    else if (out_type == JPEGX_OUT_I16) { if (nt) JPEGX_LAUNCH_INV(1, true, clamp); else JPEGX_LAUNCH_INV(1, false, clamp); }
+    else { if (nt) JPEGX_LAUNCH_INV(2, true, 1); else JPEGX_LAUNCH_INV(2, false, 1); }
+#undef JPEGX_LAUNCH_INV
     HIP_TRY(hipGetLastError());
     return JPEGX_OK;
 }

@@ -111,14 +111,18 @@ JPEGX_HD void jpegx_idct8x8_f32(float (&v)[64])
 // Rigorous bound on |fp32 fast-tier coefficient - float64 reference coefficient| for a block
 // whose samples have absolute sum S (any fp32 inputs).  Derivation in DESIGN.md ("error
 // bound"): every intermediate of either pass is bounded by the running absolute sums, each
-// 1-D output sees at most 6 roundings on its dependency chain (1 butterfly add, <=4 fma/mul,
-// constants rounded to fp32), the second pass amplifies first-pass errors by at most
-// sum|C[k][i]| <= 8 -- first order 12 u S with u = 2^-24; quantisation adds <= 2 u S (fp32
-// reciprocal and product).  16 u S = 2^-20 S leaves a margin for second-order terms.
+// 1-D output sees at most 6 roundings on a term's path (1 butterfly add, the fp32 rounding of
+// the cosine, <=4 mul/fma roundings), so pass 1 errs by <= 6 u R_i per row (R_i = row abs sum);
+// pass 2 propagates sum_i |C[k][i]| 6 u R_i <= 6 u S and adds <= 6 u S of its own: 12 u S with
+// u = 2^-24; the quantiser's fp32 reciprocal and product add <= 2 u S.  First order 14 u S;
+// 16 u S = 2^-20 S is used (margin for second-order terms).
 JPEGX_HD float jpegx_fwd_err_bound(float S) { return S * 0x1p-20f; }
 
-// Same for the inverse: |output error| <= 12 u * (1/4) * sum|Z| (<= 2^-22 * sum|Z| with margin).
-JPEGX_HD float jpegx_inv_err_bound(float S) { return S * 0x1p-22f; }
+// Same for the inverse with S = sum|Z| over the dequantised block: each pass scales by <= 1/4 and
+// puts <= 6 roundings on a term's path, so pass 1 errs by <= 1.5 u T_j per column (T_j = column
+// abs sum), pass 2 propagates 1/4 of that and adds as much again: 0.75 u S; an inexact fp32
+// dequantisation product adds <= u S / 16.  First order 0.8125 u S; 1.125 u S is used.
+JPEGX_HD float jpegx_inv_err_bound(float S) { return S * 0x1.2p-24f; }
 
 // ---------------------------------------------------------------------------------------------
 // fp64 exact tier (reference operation order)

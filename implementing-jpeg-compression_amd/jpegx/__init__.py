@@ -22,6 +22,8 @@ Q_NONE, Q_DISCARD, Q_DIVIDE, Q_QTABLE = 0, 1, 2, 3
 MODE_BY_NAME = {"none": Q_NONE, "discard": Q_DISCARD, "divide": Q_DIVIDE, "qtable": Q_QTABLE}
 F_PIXEL_INPUT = 1
 F_CLAMP_U8 = 2
+F_TUNE_NO_NT = 0x100
+F_TUNE_NO_STRIP = 0x200
 OUT_F32, OUT_I16, OUT_U8 = 0, 1, 2
 _OUT_DTYPES = {OUT_F32: np.float32, OUT_I16: np.int16, OUT_U8: np.uint8}
 _OUT_BY_NAME = {"f32": OUT_F32, "i16": OUT_I16, "u8": OUT_U8}
@@ -241,7 +243,7 @@ def is_pixel_like(a):
     return bool(np.all(a >= 0) and np.all(a < 512) and np.all(s == np.rint(s)))
 
 
-def forward_fused(plane, mode="qtable", param=0.0, pixel_input=None):
+def forward_fused(plane, mode="qtable", param=0.0, pixel_input=None, flags_extra=0):
     """fp32 plane (H, W) -> int16 (H/8, W/8, 64): BasisChange+Quantization+ZigzagOrder.execute."""
     a = _plane(plane, np.float32)
     h, w = a.shape
@@ -249,7 +251,7 @@ def forward_fused(plane, mode="qtable", param=0.0, pixel_input=None):
         pixel_input = is_pixel_like(a)
     out = np.empty((h // 8, w // 8, 64), dtype=np.int16)
     check(lib().jpegx_host_forward_fused(a.ctypes.data, h, w, w, mode_of(mode), float(param),
-                                         F_PIXEL_INPUT if pixel_input else 0, out.ctypes.data),
+                                         (F_PIXEL_INPUT if pixel_input else 0) | flags_extra, out.ctypes.data),
           "jpegx_host_forward_fused")
     return out
 

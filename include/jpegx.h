@@ -54,6 +54,9 @@ typedef enum jpegx_quant_mode {
                                   (8-bit pixels, or their 2x2/4x4 means), so partial sums are exact   \
                                   in fp32; lets the kernel use DC as the error-bound scale            */
 #define JPEGX_F_CLAMP_U8 2u    /* inverse: fuse the clamp to [0,255] of pipeline/normalization.py:10-14 */
+/* tuning switches (A/B measurements in one process; results are identical either way) */
+#define JPEGX_F_TUNE_NO_NT 0x100u /* use the default cache policy instead of nontemporal accesses */
+#define JPEGX_F_TUNE_NO_STRIP 0x200u /* forward: per-lane global loads instead of the LDS-DMA strip  */
 
 /* output element type of jpegx_inverse_fused */
 typedef enum jpegx_out_type {

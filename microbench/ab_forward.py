@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Interleaved A/B timing of fused-kernel variants in ONE process (guide rule 24).
+
+usage: python microbench/ab_forward.py [--kind noise] [--planes 16] [--rounds 7] name=flagshex ...
+e.g.   python microbench/ab_forward.py nt=0x1 plain=0x101
+Each variant is timed as `--iters` back-to-back launches between two HIP events; rounds are
+interleaved across variants; prints median / min ms per launch and GB/s (384 B per block).
+"""
+import argparse
+import os
+import statistics
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "implementing-jpeg-compression_amd"))
+import jpegx  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("variants", nargs="+")
+    ap.add_argument("--kind", default="noise")
+    ap.add_argument("--planes", type=int, default=16)
+    ap.add_argument("--size", type=int, default=4096)
+    ap.add_argument("--rounds", type=int, default=7)
+    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--direction", default="forward", choices=["forward", "inverse"])
+    ap.add_argument("--out-type", default="f32")
+    a = ap.parse_args()
+    jpegx.require_device()
+    L = jpegx.lib()
+    size, planes = a.size, a.planes
+    H, W = size * planes, size
+    nblk = (H // 8) * (W // 8)
+    plane_buf = jpegx.DeviceBuffer(H * W * 4)
+    zz_buf = jpegx.DeviceBuffer(H * W * 2)
+    for p in range(planes):
+        jpegx.generate_plane_device(plane_buf.ptr + p * size * size * 4, size, size, a.kind, seed=0, plane=p)
+    jpegx.forward_fused_device(plane_buf.ptr, H, W, zz_buf.ptr, "qtable", 0.0, jpegx.F_PIXEL_INPUT)
+    jpegx.check(L.jpegx_device_synchronize())
+    variants = [(v.split("=")[0], int(v.split("=")[1], 0)) for v in a.variants]
+    ot = {"f32": 0, "i16": 1, "u8": 2}[a.out_type]
+
+    def launch(flags):
+        if a.direction == "forward":
+            jpegx.forward_fused_device(plane_buf.ptr, H, W, zz_buf.ptr, "qtable", 0.0, flags)
+        else:
+            jpegx.inverse_fused_device(zz_buf.ptr, H, W, plane_buf.ptr, "qtable", 0.0, flags, out_type=ot)
+
+    times = {n: [] for n, _ in variants}
+    e0, e1 = jpegx.Event(), jpegx.Event()
+    for n, f in variants:
+        launch(f)
+    jpegx.check(L.jpegx_device_synchronize())
+    for _ in range(a.rounds):
+        for n, f in variants:
+            e0.record()
+            for _ in range(a.iters):
+                launch(f)
+            e1.record()
+            e1.synchronize()
+            times[n].append(e0.elapsed_ms(e1) / a.iters)
+    for n, f in variants:
+        med, mn = statistics.median(times[n]), min(times[n])
+        print("%-12s flags=0x%03x  median %.4f ms  min %.4f ms  %.1f GB/s (median)  %.1f Mblocks/s"
+              % (n, f, med, mn, 384 * nblk / med / 1e6, nblk / med / 1e3))
+
+
+if __name__ == "__main__":
+    main()

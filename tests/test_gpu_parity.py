@@ -164,3 +164,18 @@ def test_bad_arguments_raise(gpu):
         gpu.forward_fused(np.zeros((8, 8), np.float32), "divide", 0.0)
     with pytest.raises(gpu.JpegxError):
         gpu.forward_fused(np.zeros((8, 8), np.float32), "bogus")
+
+
+@pytest.mark.parametrize("flags", [0x100, 0x200, 0x300])
+@pytest.mark.parametrize("kind", ["noise", "smooth"])
+def test_forward_tuning_variants_are_bit_identical(gpu, kind, flags):
+    """Cache-policy and LDS-strip variants of the fused forward kernel give the same integers."""
+    a = gpu.synth.generate_plane(kind, 256, 1024, seed=31)          # W/8 = 128: strip variant eligible
+    want = oracle.forward_f32(a, "qtable")
+    for pixel in (True, False):
+        assert np.array_equal(gpu.forward_fused(a, "qtable", pixel_input=pixel, flags_extra=flags), want)
+    for mode, param in (("none", 0.0), ("divide", 7.0), ("discard", 3.0)):
+        assert np.array_equal(gpu.forward_fused(a, mode, param, flags_extra=flags), oracle.forward_f32(a, mode, param))
+    ties = np.tile(np.load(__import__("os").path.join(__import__("conftest").GOLDEN, "case_ties128.npz"))["pre"], (1, 4))
+    assert np.array_equal(gpu.forward_fused(ties.astype(np.float32), "qtable", flags_extra=flags),
+                          oracle.forward_f32(ties.astype(np.float32), "qtable"))
