@@ -219,6 +219,16 @@ def main():
                   "note": "ncclGather-style torch.distributed.gather of every rank's int16 stream; "
                           "not part of `value` (compute phase), see DESIGN.md multi-GPU"}
 
+    # HBM traffic per launch from the committed rocprofv3 PMC passes of this same command
+    # (profiles/summarize.py; FETCH_SIZE doubled per the gfx950 correction).  Not collected live.
+    traffic = None
+    try:
+        with open(os.path.join(REPO, "profiles", "r01_forward_summary.json")) as f:
+            prof = json.load(f)
+        if int(prof["kernel_trace"]["grid"]) == blocks_per_step and args.mode == "qtable":
+            traffic = prof["hbm_traffic"]["total_bytes_per_launch"]
+    except Exception:
+        traffic = None
     achieved = BYTES_PER_BLOCK * blocks_per_step / (kernel_ms * 1e-3) / 1e9
     result = {
         "metric": "M 8x8 blocks/sec (DCT+quant+zigzag fused forward)",
@@ -232,7 +242,9 @@ def main():
                    "planes_per_step_per_gpu": planes, "blocks_per_step_per_gpu": blocks_per_step,
                    "parallelism": "planes sharded per GPU, no data-path collective in the timed region"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                     "traffic_source": "profiles/r01_forward_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                       "passes of this command; bytes per launch)" if traffic else None,
                      "kernel": "k_forward_fused_strip<3,nt>", "kernel_ms": round(kernel_ms, 4),
                      "algorithmic_bytes_per_launch": BYTES_PER_BLOCK * blocks_per_step},
         "exact_tier_block_fraction": round(exact_frac, 5),
