@@ -48,6 +48,10 @@ def parse_args():
     ap.add_argument("--spinup-ms", type=float, default=60.0,
                     help="untimed launches before the W warm-up steps so that the GPU leaves its idle clocks "
                          "(a launch is ~0.25 ms; without this the first ~10 ms run ~10 %% slower)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the control flow)")
+    ap.add_argument("--share-device", action="store_true",
+                    help="rehearsal only: every rank uses GPU 0 (needs --backend gloo)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
@@ -106,8 +110,13 @@ def main():
     if world > 1:
         import torch
         import torch.distributed as dist
+        if args.share_device:
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
     jpegx.check(L.jpegx_set_device(local_rank if world > 1 else 0), "jpegx_set_device")
 
     size, planes = args.size, args.planes
@@ -198,12 +207,12 @@ def main():
     # --- RCCL gather of the coefficient stream to rank 0 (separately timed) -----------------------
     gather = None
     if dist is not None and not args.no_gather:
-        gl = [torch.empty_like(t_out) for _ in range(world)] if rank == 0 else None
-        dist.gather(t_out, gl, dst=0)                      # warm-up / connection setup
+        from jpegx.multigpu import gather_stream
+        gl = gather_stream(t_out, dst=0)                   # warm-up / connection setup
         torch.cuda.synchronize()
         dist.barrier()
         tg = time.perf_counter()
-        dist.gather(t_out, gl, dst=0)
+        gl = gather_stream(t_out, dst=0)
         torch.cuda.synchronize()
         dist.barrier()
         tg = time.perf_counter() - tg
@@ -216,7 +225,8 @@ def main():
         gather = {"ms": round(tg * 1e3, 3), "bytes_into_root": out_bytes * (world - 1),
                   "GBps_into_root": round(out_bytes * (world - 1) / tg / 1e9, 2),
                   "xgmi_bound_GBps": 7 * 153, "root_copy_ok": ok,
-                  "note": "ncclGather-style torch.distributed.gather of every rank's int16 stream; "
+                  "note": "jpegx.multigpu.gather_stream: torch.distributed.gather (RCCL) of every rank's int16 "
+                          "stream as raw bytes; "
                           "not part of `value` (compute phase), see DESIGN.md multi-GPU"}
 
     # HBM traffic per launch from the committed rocprofv3 PMC passes of this same command

@@ -1,0 +1,169 @@
+"""Codec facade and configuration with the reference's names (reference: pipeline/__init__.py).
+
+``compress_band`` / ``decompress_band`` walk the registered steps like the reference, except
+that for the accelerated configuration (transform 'DCT', dct_size 8) the three hot steps --
+BasisChange, Quantization, ZigzagOrder -- are replaced by ONE fused GPU kernel launch
+(libjpegx ``jpegx_forward_fused`` / ``jpegx_inverse_fused``) whose integer output is bit-exact
+with the step-by-step float64 pipeline.  There is no CPU fallback for the accelerated
+configuration: without libjpegx.so or a GPU the call raises ``jpegx.JpegxError``.
+"""
+import json
+
+import numpy as np
+
+import file_format
+from quantizers import DiscardingQuantizer, DivisionQuantizer, JpegQuantizationTable, RoundingQuantizer
+from util import band_to_array
+from . import (basis_change, dct_padding, normalization, padding, quantization,  # noqa: F401  (registration)
+               rle_byte_stream, run_length_encoding, subsampling, zigzag_order)
+from .base import step_classes
+
+
+class BadQuantizationError(Exception):
+    pass
+
+
+class QuantizationMethod:
+    """Named quantiser + its keyword parameters (pipeline/__init__.py:13-47)."""
+    name_to_quantizer = {
+        "none": RoundingQuantizer,
+        "discard": DiscardingQuantizer,
+        "divide": DivisionQuantizer,
+        "qtable": JpegQuantizationTable,
+    }
+
+    def __init__(self, name, **kwargs):
+        self.name = name
+        self.params = kwargs
+        self.quantizer = self._get_quantizer()
+
+    def _get_quantizer(self):
+        error_msg = "name {}, params {}".format(self.name, self.params)
+        factory = self.name_to_quantizer.get(self.name)
+        if factory is None:
+            raise BadQuantizationError(error_msg)
+        try:
+            return factory(**self.params)
+        except Exception:
+            raise BadQuantizationError(error_msg)
+
+    def to_json(self):
+        d = dict(self.params)
+        d["quantization_scheme_name"] = self.name
+        return json.dumps(d)
+
+    @staticmethod
+    def from_json(s):
+        d = json.loads(s)
+        name = d.pop("quantization_scheme_name")
+        return QuantizationMethod(name, **d)
+
+    def gpu_mode(self):
+        """(mode name, scalar parameter) understood by libjpegx, or None if not expressible."""
+        q = self.quantizer
+        if self.name == "discard":
+            return ("discard", float(q.keep)) if isinstance(q.keep, (int, np.integer)) and q.keep >= 0 else None
+        if self.name == "divide":
+            return ("divide", float(q.divisor)) if q.divisor != 0 else None
+        return (self.name, 0.0) if self.name in ("none", "qtable") else None
+
+
+class Configuration:
+    """pipeline/__init__.py:50-64"""
+
+    def __init__(self, width, height, block_size=2, dct_size=8, transform="DCT", quantization=None):
+        self.width = width
+        self.height = height
+        self.block_size = block_size
+        self.dct_size = dct_size
+        self.transform = transform
+        if quantization is None:
+            quantization = QuantizationMethod("none")
+        elif quantization.name == "qtable" and dct_size != 8:
+            raise BadQuantizationError()
+        self.quantization = quantization
+
+
+def _accelerated(config):
+    return config.transform == "DCT" and config.dct_size == 8 and config.quantization.gpu_mode() is not None
+
+
+def _hot_forward(pre, config):
+    """Steps 4+5+6 on the plane that leaves step 3: one fused launch when the samples are exact in
+    fp32 (always the case for 8-bit data with block_size 1, 2, 4, ...), else the exact float64 kernels."""
+    import jpegx
+    mode, param = config.quantization.gpu_mode()
+    pre = np.asarray(pre)
+    as32 = pre.astype(np.float32)
+    if np.array_equal(as32.astype(np.float64), pre.astype(np.float64)):
+        return jpegx.forward_fused(as32, mode, param).astype(np.float64)
+    coeffs = jpegx.quantize_f64(jpegx.dct8x8_f64(pre.astype(np.float64)), mode, param)
+    return jpegx.zigzag(coeffs)
+
+
+def _hot_inverse(zz, config):
+    """Steps 6+5+4 inverted: fused launch for int16-range coefficients, float64 kernels otherwise."""
+    import jpegx
+    mode, param = config.quantization.gpu_mode()
+    zz = np.asarray(zz)
+    if zz.size and np.abs(zz).max() <= 32767 and np.array_equal(zz, np.rint(zz)) and \
+            (mode != "divide" or abs(param) * 32767 < 2 ** 24):
+        return jpegx.inverse_fused(zz.astype(np.int16), mode, param, out="f32").astype(int)
+    plane = jpegx.restore_f64(jpegx.unzigzag(zz.astype(np.float64)), mode, param)
+    return jpegx.idct8x8_f64(plane, do_round=True).astype(int)
+
+
+def compress_band(a, config):
+    """Run every registered step forward (pipeline/__init__.py:71-76)."""
+    fused = _accelerated(config)
+    for cls in step_classes:
+        if fused and cls.step_index in (5, 6) and cls in _HOT_STEPS:
+            continue                                   # folded into the fused launch below
+        if fused and cls is basis_change.BasisChange:
+            a = _hot_forward(a, config)
+            continue
+        a = cls(config).execute(a)
+    return a
+
+
+def decompress_band(compression_result, config):
+    """Run every registered step backwards (pipeline/__init__.py:79-88)."""
+    a = compression_result
+    fused = _accelerated(config)
+    for cls in reversed(step_classes):
+        if fused and cls.step_index in (4, 5) and cls in _HOT_STEPS:
+            continue
+        if fused and cls is zigzag_order.ZigzagOrder:
+            a = _hot_inverse(a, config)
+            continue
+        a = cls(config).invert(a)
+    return a
+
+
+_HOT_STEPS = (basis_change.BasisChange, quantization.Quantization, zigzag_order.ZigzagOrder)
+
+
+class CompressedData:
+    def __init__(self, y, cb, cr):
+        self.y = y
+        self.cb = cb
+        self.cr = cr
+
+
+class Jpeg:
+    """PIL image <-> container bytes (pipeline/__init__.py:98-124)."""
+
+    def __init__(self, config):
+        self.config = config
+
+    def compress(self, image):
+        bands = [compress_band(band_to_array(band), self.config) for band in image.split()]
+        return file_format.generate_data(self.config, CompressedData(*bands))
+
+    @staticmethod
+    def decompress(bytestream):
+        from PIL import Image
+        config, data = file_format.read_data(bytestream)
+        size = (config.height, config.width)
+        planes = [decompress_band(b, config).reshape(size) for b in (data.y, data.cb, data.cr)]
+        return Image.fromarray(np.dstack(planes).astype(np.uint8), mode="YCbCr")

@@ -1,0 +1,46 @@
+"""Step 5: per-block quantisation (reference: pipeline/quantization.py).
+
+With dct_size 8 and real data the whole plane is quantised by one exact float64 kernel launch
+(jpegx_quantize_f64 / jpegx_restore_f64); otherwise the configured quantiser object is applied
+block by block on the host, as in the reference.
+"""
+import numpy as np
+
+from .base import AlgorithmStep
+
+_MODES = {"none": "none", "discard": "discard", "divide": "divide", "qtable": "qtable"}
+
+
+class Quantization(AlgorithmStep):
+    step_index = 5
+
+    def _gpu_args(self, array):
+        """(mode, param) when the plane can go through libjpegx, else None."""
+        cfg = self._config
+        method = cfg.quantization
+        if (cfg.dct_size != 8 or array.ndim != 2 or array.size == 0 or array.shape[0] % 8 or array.shape[1] % 8
+                or array.dtype.kind not in "fiu" or method.name not in _MODES):
+            return None
+        if method.name == "discard":
+            keep = method.quantizer.keep
+            return ("discard", float(keep)) if isinstance(keep, (int, np.integer)) and keep >= 0 else None
+        if method.name == "divide":
+            d = method.quantizer.divisor
+            return ("divide", float(d)) if d != 0 else None
+        return method.name, 0.0
+
+    def _run(self, array, gpu_fn, attr):
+        array = np.asarray(array)
+        args = self._gpu_args(array)
+        if args is not None:
+            import jpegx
+            return getattr(jpegx, gpu_fn)(array.astype(np.float64), *args).astype(array.dtype)
+        res = np.zeros(array.shape, dtype=array.dtype)
+        self.apply_blockwise(array, getattr(self._config.quantization.quantizer, attr), self._config.dct_size, res)
+        return res
+
+    def execute(self, array):
+        return self._run(array, "quantize_f64", "quantize")
+
+    def invert(self, array):
+        return self._run(array, "restore_f64", "restore")

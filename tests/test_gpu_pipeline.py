@@ -1,0 +1,110 @@
+"""GPU: the reference-compatible step classes and the codec facade, driven exactly like the
+reference's own tests drive them (tests/integration_tests.py, tests/zigzag_tests.py ...), with
+the reference's outputs (golden vectors) as the expectation."""
+import numpy as np
+import pytest
+
+import pipeline
+import transforms
+from conftest import CASES
+from pipeline import Configuration, QuantizationMethod, compress_band, decompress_band
+from pipeline.basis_change import BasisChange
+from pipeline.quantization import Quantization
+from pipeline.rle_byte_stream import RleBytestream
+from pipeline.run_length_encoding import RunLengthEncoding
+from pipeline.zigzag_order import ZigzagOrder
+
+pytestmark = pytest.mark.gpu
+
+METHODS = [("qtable", lambda: QuantizationMethod("qtable")), ("none", lambda: QuantizationMethod("none")),
+           ("divide40", lambda: QuantizationMethod("divide", divisor=40)),
+           ("discard2", lambda: QuantizationMethod("discard", keep=2))]
+
+
+def config_for(c, method):
+    h, w = c["input"].shape
+    return Configuration(width=w, height=h, block_size=int(c["block_size"]), dct_size=8, transform="DCT",
+                         quantization=method)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_step_classes_reproduce_the_reference_arrays(gpu, golden, case):
+    c = golden(case)
+    for suffix, mk in METHODS:
+        cfg = config_for(c, mk())
+        dct = BasisChange(cfg).execute(c["pre"])
+        assert dct.dtype == np.float64 and np.array_equal(dct, c["dct"])
+        q = Quantization(cfg).execute(dct)
+        assert np.array_equal(q, c["q_" + suffix].astype(np.float64))
+        zz = ZigzagOrder(cfg).execute(q)
+        assert zz.shape == c["zz_" + suffix].shape and np.array_equal(zz, c["zz_" + suffix].astype(np.float64))
+        back = ZigzagOrder(cfg).invert(zz)
+        assert np.array_equal(back, q)
+        rest = Quantization(cfg).invert(back)
+        assert np.array_equal(rest, c["restore_" + suffix].astype(np.float64))
+        rec = BasisChange(cfg).invert(rest)
+        assert rec.dtype.kind == "i" and np.array_equal(rec, c["idct_" + suffix])
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_compress_band_and_back_match_the_reference(gpu, golden, case):
+    """compress_band's hidden hot-path output (recovered by undoing the entropy stage) and
+    decompress_band's final band equal the reference's, for all four quantisers."""
+    c = golden(case)
+    band = c["input"].astype(np.int64)
+    for suffix, mk in METHODS:
+        cfg = config_for(c, mk())
+        blob = compress_band(band, cfg)
+        assert isinstance(blob, bytes)
+        zz = RunLengthEncoding(cfg).invert(RleBytestream(cfg).invert(blob))
+        assert np.array_equal(zz, c["zz_" + suffix])
+        restored = decompress_band(blob, cfg)
+        assert np.array_equal(restored, c["band_" + suffix])
+
+
+def test_reference_integration_cases(gpu):
+    """/root/reference/tests/integration_tests.py:11-48 with its tolerances."""
+    original = np.arange(128).reshape(8, 16)
+    cfg = Configuration(width=16, height=8, block_size=3)          # means k/9: float64 exact-kernel path
+    assert np.allclose(original, decompress_band(compress_band(original, cfg), cfg), rtol=1)
+    cfg = Configuration(width=16, height=8, block_size=3, transform="DFT")
+    assert np.allclose(original, decompress_band(compress_band(original, cfg), cfg), rtol=1)
+    small = np.arange(6).reshape(2, 3)
+    cfg = Configuration(width=3, height=2, block_size=1)
+    assert np.allclose(small, decompress_band(compress_band(small, cfg), cfg), rtol=0.000001)
+
+
+def test_non_fp32_representable_input_takes_the_exact_path(gpu):
+    """block_size 3 produces thirds: the facade must not round them to fp32."""
+    import oracle
+    rng = np.random.default_rng(5)
+    band = rng.integers(0, 256, (48, 72))
+    cfg = Configuration(width=72, height=48, block_size=3, quantization=QuantizationMethod("qtable"))
+    pre = band.reshape(16, 3, 24, 3).mean(axis=(1, 3))
+    want = oracle.zigzag_plane(oracle.quant_plane(oracle.dct_plane(pre), "qtable"))
+    blob = compress_band(band, cfg)
+    zz = RunLengthEncoding(cfg).invert(RleBytestream(cfg).invert(blob))
+    assert np.array_equal(zz, want)
+
+
+def test_dct_class_on_the_gpu(gpu, tables):
+    d = transforms.DCT(8)
+    a = np.arange(64).reshape(8, 8)
+    y = d.transform_2d(a)
+    import oracle
+    assert np.array_equal(y, oracle.dct_plane(a))
+    assert np.allclose(a, d.transform_2d_inverse(y), rtol=0.01)
+
+
+def test_jpeg_facade_round_trip_through_pil(gpu):
+    from PIL import Image
+    from jpegx import synth
+    h, w = 40, 56
+    rgb = np.dstack([synth.generate_plane("smooth", h, w, seed=s, dtype=np.uint8) for s in (1, 2, 3)])
+    im = Image.fromarray(rgb, mode="RGB").convert("YCbCr")
+    cfg = Configuration(width=w, height=h, block_size=2, dct_size=8, quantization=QuantizationMethod("qtable"))
+    blob = pipeline.Jpeg(cfg).compress(im)
+    out = pipeline.Jpeg.decompress(blob)
+    assert out.size == (w, h) and out.mode == "YCbCr"
+    err = np.abs(np.asarray(out, dtype=np.int64)[..., 0] - np.asarray(im, dtype=np.int64)[..., 0])
+    assert err.mean() < 12

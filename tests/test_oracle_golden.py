@@ -1,0 +1,86 @@
+"""The oracle (oracle/jpegx_oracle.c) against every golden vector produced by the unmodified
+reference, and against the reference's own known-answer tests for this path.  CPU only."""
+import numpy as np
+import pytest
+
+import oracle
+from conftest import CASES, MODES
+
+
+def test_tables_match_reference(tables):
+    t = oracle.tables()
+    for key in ("dct_matrix", "dct_normalized", "norm_diag", "qtable", "zigzag8"):
+        assert np.array_equal(t[key], tables[key]), key
+    # the standard JPEG zigzag order
+    assert t["zigzag8"][:10].tolist() == [0, 1, 8, 16, 9, 2, 3, 10, 17, 24]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_forward_stages_bit_identical(golden, case):
+    c = golden(case)
+    dct = oracle.dct_plane(c["pre"])
+    assert np.array_equal(dct, c["dct"])                          # float64, bit for bit
+    for suffix, mode, param in MODES:
+        q = oracle.quant_plane(dct, mode, param)
+        assert np.array_equal(q, c["q_" + suffix])
+        assert np.array_equal(oracle.zigzag_plane(q), c["zz_" + suffix])
+        fused = oracle.forward_f32(c["pre"].astype(np.float32), mode, param)
+        assert np.array_equal(fused, c["zz_" + suffix])
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_inverse_stages_bit_identical(golden, case):
+    c = golden(case)
+    for suffix, mode, param in MODES:
+        r = oracle.restore_plane(oracle.unzigzag_plane(c["zz_" + suffix]), mode, param)
+        assert np.array_equal(r, c["restore_" + suffix])
+        assert np.array_equal(oracle.idct_plane(r), c["idct_" + suffix])
+        assert np.array_equal(oracle.inverse_i16(c["zz_" + suffix], mode, param), c["idct_" + suffix])
+
+
+def test_tie_stress_blocks_are_really_ties(golden):
+    """The tie fixture holds exact DC ties and (4,4) ties; the reference's answers are pinned."""
+    c = golden("ties128")
+    kinds = np.load(__import__("os").path.join(__import__("conftest").GOLDEN, "ties_kinds.npy"))
+    dc = c["dct"][0::8, 0::8]
+    assert np.all((dc[(kinds == 1) | (kinds == 3)] % 16) == 8)
+    c44 = c["dct"][4::8, 4::8][(kinds == 2) | (kinds == 3)]
+    assert np.all(np.abs(np.abs(c44 / 68.0 % 1.0) - 0.5) < 1e-9)
+
+
+def test_mean_pool_matches_reference(golden):
+    c = golden("pooled128")
+    assert np.array_equal(oracle.mean_pool(c["input"].astype(np.float64), 2), c["pre"])
+
+
+def test_reference_known_answers_quantizers():
+    """/root/reference/tests/quantization_tests.py:10-54 restated on 8x8-tiled planes."""
+    a = np.zeros((8, 8))
+    a[0, :3] = [80, 24, 169]
+    assert oracle.quant_plane(a, "divide", 40)[0, :3].tolist() == [2, 1, 4]
+    assert oracle.restore_plane(oracle.quant_plane(a, "divide", 40), "divide", 40)[0, :3].tolist() == [80, 40, 160]
+    b = np.zeros((8, 8))
+    b[:2, :2] = [[3.4, 8.0], [0, 0.6]]
+    assert oracle.quant_plane(b, "none")[:2, :2].tolist() == [[3, 8], [0, 1]]
+    d = np.arange(64, dtype=float).reshape(8, 8)
+    q = oracle.quant_plane(d, "discard", 2)
+    assert q[:2, :2].tolist() == [[0, 1], [8, 9]] and q[2:].sum() == 0 and q[:, 2:].sum() == 0
+
+
+def test_reference_dct_round_trip_property():
+    """/root/reference/tests/basis_change_tests.py:32-38: inverse(forward(arange(64))) == input."""
+    a = np.arange(64, dtype=float).reshape(8, 8)
+    back = oracle.idct_plane(oracle.dct_plane(a), rounded=False)
+    assert np.allclose(a, back, rtol=0.01)
+    assert np.abs(back - a).max() < 1e-10
+
+
+def test_python_loop_restatement_agrees(golden):
+    from oracle import ref_loop
+    c = golden("smooth64")
+    assert np.array_equal(ref_loop.forward_qtable(c["pre"]), c["zz_qtable"])
+
+
+def test_bad_shapes_are_rejected():
+    with pytest.raises(ValueError):
+        oracle.dct_plane(np.zeros((12, 8)))
