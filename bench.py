@@ -101,10 +101,9 @@ def main():
         raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
                          % (args.gpus, args.gpus))
 
-    import jpegx
-    jpegx.require_device()
-    L = jpegx.lib()
-
+    # torch (only needed for the N > 1 process group) must be imported BEFORE libjpegx.so is loaded so
+    # that both resolve to ONE HIP runtime (torch bundles its own libamdhip64; loading /opt/rocm's first
+    # leaves torch without devices -- measured on the GPU box).
     dist = None
     torch = None
     if world > 1:
@@ -117,6 +116,9 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group("gloo")
+    import jpegx
+    jpegx.require_device()
+    L = jpegx.lib()
     jpegx.check(L.jpegx_set_device(local_rank if world > 1 else 0), "jpegx_set_device")
 
     size, planes = args.size, args.planes
