@@ -64,7 +64,7 @@ struct QuantParams {
                      // inverse: fp32 multiplier per natural index
     double param;    // keep / divisor
     int mode;
-    int pad;
+    int tune;        // bit0: skip the exact tier (timing experiments only -- results are then NOT bit-exact)
 };
 
 // LDS tile of one wave: 64 rows (blocks) x 128 B, 16-B chunks XOR-swizzled by the row so that
@@ -244,6 +244,7 @@ __global__ __launch_bounds__(64) void k_forward_fused(const float *__restrict__ 
         atomicAdd(&counters[0], (unsigned long long)__popcll(flagged));
         atomicAdd(&counters[1], (unsigned long long)min(64, nblk - g0));
     }
+    if (prm.tune & 1) flagged = 0;
     __syncthreads();
     while (flagged) {
         const int b = __ffsll((long long)flagged) - 1;
@@ -384,6 +385,7 @@ __global__ __launch_bounds__(64) void k_forward_fused_strip(const float *__restr
         atomicAdd(&counters[0], (unsigned long long)__popcll(flagged));
         atomicAdd(&counters[1], (unsigned long long)min(64, nblk - g0));
     }
+    if (prm.tune & 1) flagged = 0;
     while (flagged) {   // exact tier, inputs re-read from the strip still resident in LDS
         const int b = __ffsll((long long)flagged) - 1;
         flagged &= flagged - 1;
@@ -427,8 +429,12 @@ __global__ __launch_bounds__(64) void k_inverse_fused(const int16_t *__restrict_
                                                       QuantParams prm, int clamp, void *__restrict__ outv,
                                                       size_t opitch, unsigned long long *counters)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
-    double *sA = reinterpret_cast<double *>(lds + TILE_BYTES);
+    // f32 output is staged through an 8-row x 2 KiB strip (coalesced 1 KiB stores); the narrower
+    // i16 / u8 rows are already contiguous per store instruction and go out directly.
+    constexpr int LDSB = (OUT == 0) ? STRIP_LDS_BYTES : LDS_BYTES;
+    constexpr int SCR = (OUT == 0) ? STRIP_BYTES : TILE_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[LDSB];
+    double *sA = reinterpret_cast<double *>(lds + SCR);
     double *sM = sA + 64;
     float *sP = reinterpret_cast<float *>(sA);  // 64 patched samples (reuses sA after the exchange)
 
@@ -437,19 +443,23 @@ __global__ __launch_bounds__(64) void k_inverse_fused(const int16_t *__restrict_
     const int g = g0 + lane;
     const bool valid = g < nblk;
 
-    // coalesced read-in of the wave's 8 KiB, parked in the swizzled tile
-    const unsigned char *srcb = reinterpret_cast<const unsigned char *>(in) + (size_t)g0 * 128;
+    // the wave's 8 KiB of coefficients -> swizzled LDS tile by LDS-DMA: piece i fills tile rows
+    // 8i..8i+7; lane l lands in (row 8i + l/8, slot l%8), which must hold chunk slot ^ (row & 7).
+    {
+        const int row0 = lane >> 3, c = (lane & 7) ^ (lane >> 3);
+        const int last = nblk - 1 - g0;   // rows past the end re-read the last block
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int row = i * 8 + (lane >> 3), c = lane & 7;
-        u32x4 q = {0u, 0u, 0u, 0u};
-        if (g0 + row < nblk) q = ld_u32x4<NT>(srcb + (size_t)row * 128 + c * 16);
-        *reinterpret_cast<u32x4 *>(lds + tile_off(row, c)) = q;
+        for (int i = 0; i < 8; ++i) {
+            const int row = min(i * 8 + row0, last);
+            const unsigned char *src = reinterpret_cast<const unsigned char *>(in) + (size_t)(g0 + row) * 128 + c * 16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(lds + i * 1024), 16, 0, NT ? 2 : 0);
+        }
     }
     __syncthreads();
 
     float v[64];
-    float S = 0.f;
+    float Sac = 0.f;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
         const uint4 q = *reinterpret_cast<const uint4 *>(lds + tile_off(lane, c));
@@ -463,12 +473,12 @@ __global__ __launch_bounds__(64) void k_inverse_fused(const int16_t *__restrict_
                 const int z = h ? ((int)w[s] >> 16) : (int)(short)(w[s] & 0xFFFFu);
                 const float d = (float)z * prm.rq32[n];  // quantizers.py:8-9,30-31,51-53
                 v[n] = d;
-                S += fabsf(d);
+                if (n != 0) Sac += fabsf(d);
             }
         }
     }
+    const float E = jpegx_inv_err_bound(fabsf(v[0]), Sac);
     jpegx_idct8x8_f32(v);
-    const float E = jpegx_inv_err_bound(S);
 
     float worst = 0.f;
 #pragma unroll
@@ -482,6 +492,7 @@ __global__ __launch_bounds__(64) void k_inverse_fused(const int16_t *__restrict_
         atomicAdd(&counters[0], (unsigned long long)__popcll(flagged));
         atomicAdd(&counters[1], (unsigned long long)min(64, nblk - g0));
     }
+    if (prm.tune & 1) flagged = 0;
     while (flagged) {
         const int b = __ffsll((long long)flagged) - 1;
         flagged &= flagged - 1;
@@ -501,20 +512,44 @@ __global__ __launch_bounds__(64) void k_inverse_fused(const int16_t *__restrict_
         __syncthreads();
     }
 
-    if (!valid) return;
-    const int by = g / wb, bx = g - by * wb;
     if (OUT == 0) {
-        float *o = reinterpret_cast<float *>(outv) + (size_t)by * 8 * opitch + (size_t)bx * 8;
+        // park the lane's 8 x 32 B in the strip layout of the forward kernel (chunk c at slot
+        // strip_swz(c)), then 16 coalesced 1 KiB stores; the coefficient tile is dead by now.
+        __syncthreads();
+        const int f = ((lane >> 2) ^ (lane >> 3)) & 1;
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             float x[8];
 #pragma unroll
             for (int c = 0; c < 8; ++c) x[c] = clamp ? fminf(fmaxf(v[r * 8 + c], 0.f), 255.f) : v[r * 8 + c];
-            float *row = o + (size_t)r * opitch;
-            st_f32x4<NT>(row, f32x4{x[0], x[1], x[2], x[3]});
-            st_f32x4<NT>(row + 4, f32x4{x[4], x[5], x[6], x[7]});
+            *reinterpret_cast<f32x4 *>(lds + r * 2048 + ((2 * lane + f) << 4)) = f32x4{x[0], x[1], x[2], x[3]};
+            *reinterpret_cast<f32x4 *>(lds + r * 2048 + ((2 * lane + (f ^ 1)) << 4)) = f32x4{x[4], x[5], x[6], x[7]};
         }
-    } else if (OUT == 1) {
+        __syncthreads();
+        float *dstp[2];
+        bool ok[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int c = strip_swz(64 * j + lane);
+            const int gb = g0 + (c >> 1);
+            ok[j] = gb < nblk;
+            const int gbc = ok[j] ? gb : nblk - 1;
+            const int by = gbc / wb, bx = gbc - by * wb;
+            dstp[j] = reinterpret_cast<float *>(outv) + (size_t)by * 8 * opitch + (size_t)bx * 8 + (c & 1) * 4;
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const f32x4 t = *reinterpret_cast<const f32x4 *>(lds + r * 2048 + j * 1024 + lane * 16);
+                if (ok[j]) st_f32x4<NT>(dstp[j] + (size_t)r * opitch, t);
+            }
+        }
+        return;
+    }
+    if (!valid) return;
+    const int by = g / wb, bx = g - by * wb;
+    if (OUT == 1) {
         int16_t *o = reinterpret_cast<int16_t *>(outv) + (size_t)by * 8 * opitch + (size_t)bx * 8;
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
@@ -684,7 +719,7 @@ int fill_forward_params(int mode, double param, QuantParams *qp)
 {
     qp->mode = mode;
     qp->param = param;
-    qp->pad = 0;
+    qp->tune = 0;
     switch (mode) {
     case JPEGX_Q_NONE:
         for (int n = 0; n < 64; ++n) qp->rq32[n] = 1.0f;
@@ -712,7 +747,7 @@ int fill_inverse_params(int mode, double param, QuantParams *qp)
 {
     qp->mode = mode;
     qp->param = param;
-    qp->pad = 0;
+    qp->tune = 0;
     switch (mode) {
     case JPEGX_Q_NONE:
     case JPEGX_Q_DISCARD:
@@ -935,6 +970,7 @@ int jpegx_forward_fused_pooled(const float *d_in, int H, int W, ptrdiff_t pitch,
     QuantParams qp;
     rc = fill_forward_params(mode, param, &qp);
     if (rc) return rc;
+    if (flags & JPEGX_F_TUNE_SKIP_EXACT) qp.tune |= 1;
     hipStream_t st = (hipStream_t)stream;
     if (flags & JPEGX_F_TUNE_NO_NT) {
         if (bs == 1) return launch_forward<1, false>(d_in, H, W, pitch, qp, flags, d_out, st);
@@ -964,6 +1000,7 @@ int jpegx_inverse_fused(const int16_t *d_in, int H, int W, int mode, double para
     QuantParams qp;
     rc = fill_inverse_params(mode, param, &qp);
     if (rc) return rc;
+    if (flags & JPEGX_F_TUNE_SKIP_EXACT) qp.tune |= 1;
     const int wb = W / 8, nblk = (H / 8) * wb;
     const dim3 grid((nblk + 63) / 64), block(64);
     const int clamp = (flags & JPEGX_F_CLAMP_U8) ? 1 : 0;

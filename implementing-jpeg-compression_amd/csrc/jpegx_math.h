@@ -118,11 +118,17 @@ JPEGX_HD void jpegx_idct8x8_f32(float (&v)[64])
 // 16 u S = 2^-20 S is used (margin for second-order terms).
 JPEGX_HD float jpegx_fwd_err_bound(float S) { return S * 0x1p-20f; }
 
-// Same for the inverse with S = sum|Z| over the dequantised block: each pass scales by <= 1/4 and
-// puts <= 6 roundings on a term's path, so pass 1 errs by <= 1.5 u T_j per column (T_j = column
-// abs sum), pass 2 propagates 1/4 of that and adds as much again: 0.75 u S; an inexact fp32
-// dequantisation product adds <= u S / 16.  First order 0.8125 u S; 1.125 u S is used.
-JPEGX_HD float jpegx_inv_err_bound(float S) { return S * 0x1.2p-24f; }
+// Same for the inverse, for a dequantised block with DC magnitude D = |Z00| and AC abs sum
+// A = sum_{n != 0} |Z_n|.  Each pass scales AC terms by 1/4 and puts <= 6 roundings on an AC
+// term's path (1.5 u per unit of |Z|); the k = 0 input of a 1-D transform is scaled by exactly
+// 1/8 (a power of two) and only meets the 3 roundings of the final additions (3/8 u per unit).
+//   pass 1, column j :  e1 <= 3/8 u |Z0j| + 3/2 u T'_j                (T'_j = sum_{k>=1} |Zkj|)
+//   pass 2, row i    :  1/8 e1(col 0) + 1/4 sum_{k>=1} e1(col k) + 3/8 u |m_i0| + 3/2 u sum_{k>=1} |m_ik|
+//   with |m_i0| <= D/8 + T'_0/4 and |m_ik| <= |Z0k|/8 + T'_k/4 this is
+//       u (3/32 D + 9/32 (T'_0 + sum_{k>=1}|Z0k|) + 3/4 sum_{k>=1} T'_k)  <=  u (0.094 D + 0.75 A);
+// an inexact fp32 dequantisation product adds <= u (D/64 + A/16).  First order
+// u (0.11 D + 0.8125 A); the bound used is u (0.125 D + 0.875 A).
+JPEGX_HD float jpegx_inv_err_bound(float D, float A) { return fmaf(D, 0x1p-27f, A * 0x1.cp-25f); }
 
 // ---------------------------------------------------------------------------------------------
 // fp64 exact tier (reference operation order)

@@ -56,6 +56,7 @@ typedef enum jpegx_quant_mode {
 #define JPEGX_F_CLAMP_U8 2u    /* inverse: fuse the clamp to [0,255] of pipeline/normalization.py:10-14 */
 /* tuning switches (A/B measurements in one process; results are identical either way) */
 #define JPEGX_F_TUNE_NO_NT 0x100u /* use the default cache policy instead of nontemporal accesses */
+#define JPEGX_F_TUNE_SKIP_EXACT 0x400u /* TIMING ONLY: skip the float64 exact tier (output no longer bit-exact) */
 #define JPEGX_F_TUNE_NO_STRIP 0x200u /* forward: per-lane global loads instead of the LDS-DMA strip  */
 
 /* output element type of jpegx_inverse_fused */

@@ -82,14 +82,15 @@ int emul_inverse(const int16_t *in, int H, int W, int mode, double param, int32_
     for (int by = 0; by < H / 8; ++by)
         for (int bx = 0; bx < wb; ++bx) {
             const int16_t *z = in + ((size_t)by * wb + bx) * 64;
-            float v[64]; double a[64]; float S = 0.f;
+            float v[64]; double a[64]; float S = 0.f, Sac = 0.f;
             for (int p = 0; p < 64; ++p) {
                 int n = T_ZZ[p];
                 double d = jpegx_restore_ref((double)z[p], n, mode, param, T_QT);
                 a[n] = d; v[n] = (float)d; S += fabsf(v[n]);
+                if (n != 0) Sac += fabsf(v[n]);
             }
+            const float E = jpegx_inv_err_bound(fabsf(v[0]), Sac);
             jpegx_idct8x8_f32(v);
-            const float E = jpegx_inv_err_bound(S);
             double u[8], m[64], y64[64], w[8];
             for (int j = 0; j < 8; ++j) {       // columns first
                 for (int k = 0; k < 8; ++k) u[k] = T_DINV[k] * a[k * 8 + j];
@@ -107,7 +108,7 @@ int emul_inverse(const int16_t *in, int H, int W, int mode, double param, int32_
             }
             int blkflag = 0;
             for (int n = 0; n < 64; ++n) {
-                double ratio = fabs((double)v[n] - y64[n]) / (0x1p-24 * (double)(S > 0 ? S : 1));
+                double ratio = fabs((double)v[n] - y64[n]) / (double)(E > 0 ? E : 1e-30f);   /* observed error / bound */
                 if (ratio > maxratio) maxratio = ratio;
                 float r = rintf(v[n]);
                 int flag = (fabsf(v[n] - r) + E) >= 0.5f;

@@ -87,4 +87,4 @@ def test_inverse_two_tier_matches_reference(emul, golden, case, suffix, mode, pa
     emul.emul_inverse(_p(zz, ctypes.c_int16), h, w, oracle.MODE_BY_NAME[mode], ctypes.c_double(param),
                       _p(out, ctypes.c_int32), _p(st, ctypes.c_double))
     assert np.array_equal(out, c["idct_" + suffix])
-    assert st[2] < 1.125             # inverse bound is 1.125 u sum|Z|
+    assert st[2] < 1.0               # observed fp32 error / bound u (0.125 |DC| + 0.875 sum|AC|)
