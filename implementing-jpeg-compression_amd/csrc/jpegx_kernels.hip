@@ -972,14 +972,13 @@ int jpegx_forward_fused_pooled(const float *d_in, int H, int W, ptrdiff_t pitch,
     if (rc) return rc;
     if (flags & JPEGX_F_TUNE_SKIP_EXACT) qp.tune |= 1;
     hipStream_t st = (hipStream_t)stream;
-    if (flags & JPEGX_F_TUNE_NO_NT) {
-        if (bs == 1) return launch_forward<1, false>(d_in, H, W, pitch, qp, flags, d_out, st);
-        if (bs == 2) return launch_forward<2, false>(d_in, H, W, pitch, qp, flags, d_out, st);
-        return launch_forward<4, false>(d_in, H, W, pitch, qp, flags, d_out, st);
-    }
-    if (bs == 1) return launch_forward<1, true>(d_in, H, W, pitch, qp, flags, d_out, st);
-    if (bs == 2) return launch_forward<2, true>(d_in, H, W, pitch, qp, flags, d_out, st);
-    return launch_forward<4, true>(d_in, H, W, pitch, qp, flags, d_out, st);
+    // The pooled kernels read partial lines per instruction (16 B at a 32*bs-byte lane stride);
+    // nontemporal loads then refetch every line and lose 30-60 % (profiles/r01_ab_pooled.txt),
+    // so they always use the default cache policy.
+    if (bs == 2) return launch_forward<2, false>(d_in, H, W, pitch, qp, flags, d_out, st);
+    if (bs == 4) return launch_forward<4, false>(d_in, H, W, pitch, qp, flags, d_out, st);
+    if (flags & JPEGX_F_TUNE_NO_NT) return launch_forward<1, false>(d_in, H, W, pitch, qp, flags, d_out, st);
+    return launch_forward<1, true>(d_in, H, W, pitch, qp, flags, d_out, st);
 }
 
 int jpegx_forward_fused(const float *d_in, int H, int W, ptrdiff_t pitch, int mode, double param, unsigned flags,

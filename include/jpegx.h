@@ -9,8 +9,8 @@
  *   - The caller owns host buffers; device buffers are plain device pointers (from
  *     jpegx_malloc, hipMalloc or torch .data_ptr() -- they are interchangeable).
  *   - Every compute entry takes a stream handle (hipStream_t cast to void*; NULL = the
- *     default stream) and only ENQUEUES work: no allocation, no synchronisation, so calls
- *     can be captured into a hipGraph.  jpegx_host_* variants are the synchronous
+ *     default stream) and only ENQUEUES work: no allocation, no host synchronisation.
+ *     jpegx_host_* variants are the synchronous
  *     host-pointer conveniences used by the Python step classes.
  *   - One host thread per device is safe; the library keeps no mutable global state besides
  *     the thread-local error string and the current HIP device of the calling thread.

@@ -26,24 +26,27 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--direction", default="forward", choices=["forward", "inverse"])
     ap.add_argument("--out-type", default="f32")
+    ap.add_argument("--pool", type=int, default=1, help="forward: fused mean-pool factor (input is pool x larger)")
     a = ap.parse_args()
     jpegx.require_device()
     L = jpegx.lib()
     size, planes = a.size, a.planes
     H, W = size * planes, size
     nblk = (H // 8) * (W // 8)
-    plane_buf = jpegx.DeviceBuffer(H * W * 4)
+    pool = a.pool
+    plane_buf = jpegx.DeviceBuffer(H * W * 4 * pool * pool)
     zz_buf = jpegx.DeviceBuffer(H * W * 2)
     for p in range(planes):
-        jpegx.generate_plane_device(plane_buf.ptr + p * size * size * 4, size, size, a.kind, seed=0, plane=p)
-    jpegx.forward_fused_device(plane_buf.ptr, H, W, zz_buf.ptr, "qtable", 0.0, jpegx.F_PIXEL_INPUT)
+        jpegx.generate_plane_device(plane_buf.ptr + p * size * size * 4 * pool * pool, size * pool, size * pool,
+                                    a.kind, seed=0, plane=p)
+    jpegx.forward_fused_device(plane_buf.ptr, H, W, zz_buf.ptr, "qtable", 0.0, jpegx.F_PIXEL_INPUT, pool=pool)
     jpegx.check(L.jpegx_device_synchronize())
     variants = [(v.split("=")[0], int(v.split("=")[1], 0)) for v in a.variants]
     ot = {"f32": 0, "i16": 1, "u8": 2}[a.out_type]
 
     def launch(flags):
         if a.direction == "forward":
-            jpegx.forward_fused_device(plane_buf.ptr, H, W, zz_buf.ptr, "qtable", 0.0, flags)
+            jpegx.forward_fused_device(plane_buf.ptr, H, W, zz_buf.ptr, "qtable", 0.0, flags, pool=pool)
         else:
             jpegx.inverse_fused_device(zz_buf.ptr, H, W, plane_buf.ptr, "qtable", 0.0, flags, out_type=ot)
 
@@ -62,8 +65,12 @@ def main():
             times[n].append(e0.elapsed_ms(e1) / a.iters)
     for n, f in variants:
         med, mn = statistics.median(times[n]), min(times[n])
-        print("%-12s flags=0x%03x  median %.4f ms  min %.4f ms  %.1f GB/s (median)  %.1f Mblocks/s"
-              % (n, f, med, mn, 384 * nblk / med / 1e6, nblk / med / 1e3))
+        if a.direction == "forward":
+            bpb = 256 * pool * pool + 128
+        else:
+            bpb = 128 + {"f32": 256, "i16": 128, "u8": 64}[a.out_type]
+        print("%-12s flags=0x%03x  median %.4f ms  min %.4f ms  %.1f GB/s (median, %d B/block)  %.1f Mblocks/s"
+              % (n, f, med, mn, bpb * nblk / med / 1e6, bpb, nblk / med / 1e3))
 
 
 if __name__ == "__main__":

@@ -179,3 +179,55 @@ def test_forward_tuning_variants_are_bit_identical(gpu, kind, flags):
     ties = np.tile(np.load(__import__("os").path.join(__import__("conftest").GOLDEN, "case_ties128.npz"))["pre"], (1, 4))
     assert np.array_equal(gpu.forward_fused(ties.astype(np.float32), "qtable", flags_extra=flags),
                           oracle.forward_f32(ties.astype(np.float32), "qtable"))
+
+
+def test_device_api_with_pitch_stream_and_events(gpu):
+    """Device-pointer entry points: padded rows (pitch > W), a non-default stream, HIP events."""
+    import ctypes
+    L = gpu.lib()
+    h, w, pitch = 64, 520, 544                      # W/8 = 65 blocks per row: ragged strips too
+    a = gpu.synth.generate_plane("noise", h, w, seed=77)
+    padded = np.full((h, pitch), -1.0, dtype=np.float32)
+    padded[:, :w] = a
+    st = ctypes.c_void_p()
+    gpu.check(L.jpegx_stream_create(ctypes.byref(st)))
+    din, dzz, dback = gpu.DeviceBuffer(padded.nbytes), gpu.DeviceBuffer(h * w * 2), gpu.DeviceBuffer(h * pitch * 4)
+    din.upload(padded, stream=st.value)
+    e0, e1 = gpu.Event(), gpu.Event()
+    e0.record(st.value)
+    gpu.forward_fused_device(din.ptr, h, w, dzz.ptr, "qtable", 0.0, gpu.F_PIXEL_INPUT, pitch=pitch, stream=st.value)
+    gpu.check(L.jpegx_memset(dback.ptr, 0, h * pitch * 4, st.value))
+    gpu.inverse_fused_device(dzz.ptr, h, w, dback.ptr, "qtable", 0.0, 0, out_type=gpu.OUT_F32, out_pitch=pitch,
+                             stream=st.value)
+    e1.record(st.value)
+    e1.synchronize()
+    assert e0.elapsed_ms(e1) > 0.0
+    zz = dzz.download((h // 8, w // 8, 64), np.int16, stream=st.value)
+    want = oracle.forward_f32(a, "qtable")
+    assert np.array_equal(zz, want)
+    back = dback.download((h, pitch), np.float32, stream=st.value)
+    assert np.array_equal(back[:, :w].astype(np.int32), oracle.inverse_i16(want, "qtable"))
+    assert np.all(back[:, w:] == 0)                 # the padding columns are never written
+    gpu.check(L.jpegx_stream_destroy(st.value))
+    # misaligned pitch is rejected, not mis-executed
+    with pytest.raises(gpu.JpegxError):
+        gpu.forward_fused_device(din.ptr, h, w, dzz.ptr, "qtable", 0.0, gpu.F_PIXEL_INPUT, pitch=pitch + 1)
+
+
+def test_exact_tier_census_counters(gpu):
+    """jpegx_set_debug_counters reports how many blocks took the float64 tier (3-4 % on noise)."""
+    import ctypes
+    L = gpu.lib()
+    h = w = 1024
+    din, dzz, cnt = gpu.DeviceBuffer(h * w * 4), gpu.DeviceBuffer(h * w * 2), gpu.DeviceBuffer(16)
+    gpu.generate_plane_device(din.ptr, h, w, "noise", seed=1)
+    gpu.check(L.jpegx_memset(cnt.ptr, 0, 16, None))
+    gpu.check(L.jpegx_set_debug_counters(cnt.ptr))
+    try:
+        gpu.forward_fused_device(din.ptr, h, w, dzz.ptr, "qtable", 0.0, gpu.F_PIXEL_INPUT)
+        gpu.check(L.jpegx_device_synchronize())
+    finally:
+        gpu.check(L.jpegx_set_debug_counters(None))
+    flagged, total = cnt.download((2,), np.uint64)
+    assert total == (h // 8) * (w // 8)
+    assert 0.01 < flagged / total < 0.08
