@@ -147,15 +147,17 @@ __device__ __forceinline__ double coop_inv_exact(double z_own, double *sA, doubl
 // fused forward: DCT + quantise + zigzag.  VAR bit0 = PIXEL_INPUT, bit1 = DC exact.
 // BS = mean-pool factor of the fused SubSampling prologue (1 = none).
 // ------------------------------------------------------------------------------------------------
-template <int VAR, int BS, bool NT>
+template <int VAR, int BS, bool NT, int STAGED>
 __global__ __launch_bounds__(64) void k_forward_fused(const float *__restrict__ in, size_t pitch, int wb,
                                                       int nblk, QuantParams prm, int16_t *__restrict__ out,
                                                       unsigned long long *counters)
 {
     constexpr bool PIXEL = (VAR & 1) != 0;
     constexpr bool DC_EXACT = (VAR & 2) != 0;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
-    double *sA = reinterpret_cast<double *>(lds + TILE_BYTES);
+    constexpr int STAGE_BYTES = STAGED * 2 * BS * 1024;                 // staging buffer (0 if not staged)
+    constexpr int FRONT = STAGE_BYTES > TILE_BYTES ? STAGE_BYTES : TILE_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[FRONT + SCRATCH_DOUBLES * 8];
+    double *sA = reinterpret_cast<double *>(lds + FRONT);
     double *sM = sA + 64;
 
     const int lane = threadIdx.x;
@@ -175,6 +177,72 @@ __global__ __launch_bounds__(64) void k_forward_fused(const float *__restrict__ 
             v[r * 8 + 0] = lo.x; v[r * 8 + 1] = lo.y; v[r * 8 + 2] = lo.z; v[r * 8 + 3] = lo.w;
             v[r * 8 + 4] = hi.x; v[r * 8 + 5] = hi.y; v[r * 8 + 6] = hi.z; v[r * 8 + 7] = hi.w;
         }
+    } else if (STAGED) {
+        // SubSampling.execute fused (pipeline/subsampling.py:9-11), input staged through LDS: the
+        // wave's 64 blocks cover 8*BS input rows of 64 * 32*BS bytes; they are streamed in phases of
+        // 8 KiB (BS=2: two input rows = one output row; BS=4: one input row) by LDS-DMA -- whole
+        // 128-B lines, nontemporal -- and every lane folds its 2*BS chunks per row into the 8 pooled
+        // samples of the output row.  Chunk q of block b sits at slot 2BS*b + (q ^ g(b)),
+        // g(b) = (b >> (BS == 2 ? 2 : 1)) & (2BS - 1): conflict-free ds_read_b128 at a 32*BS-byte
+        // lane stride; the permutation is applied on the DMA source address.
+        constexpr int CPB = 2 * BS;                 // 16-B chunks per block and input row
+        constexpr int RPP = STAGED;                 // input rows per phase (RPP * CPB KiB of LDS)
+        constexpr int GSH = (BS == 2) ? 2 : 1;
+        // per-lane 32-bit byte offsets from the wave's first block (keeps the DMA addresses in the
+        // "scalar base + vector offset" form: the row advance is scalar arithmetic)
+        const int by0 = g0 / wb, bx0 = g0 - by0 * wb;
+        const unsigned char *base0 = reinterpret_cast<const unsigned char *>(in + ((size_t)by0 * 8 * BS) * pitch + (size_t)bx0 * 8 * BS);
+        unsigned off[CPB];
+#pragma unroll
+        for (int j = 0; j < CPB; ++j) {
+            const int slot = 64 * j + lane;
+            const int b = slot / CPB, sl = slot % CPB;
+            const int q = sl ^ ((b >> GSH) & (CPB - 1));
+            const int gb = min(g0 + b, nblk - 1);
+            const int byb = gb / wb, bxb = gb - byb * wb;
+            off[j] = (unsigned)(((size_t)(byb - by0) * 8 * BS * pitch + ((size_t)bxb - bx0) * 8 * BS + q * 4) * 4);
+        }
+        const int gq = (lane >> GSH) & (CPB - 1);
+        float acc[8];
+#pragma unroll
+        for (int ph = 0; ph < 8 * BS / RPP; ++ph) {
+            __syncthreads();                        // previous phase's LDS reads are done
+#pragma unroll
+            for (int rr = 0; rr < RPP; ++rr) {
+                const unsigned char *rowbase = base0 + (size_t)(ph * RPP + rr) * pitch * 4;
+#pragma unroll
+                for (int j = 0; j < CPB; ++j)
+                    __builtin_amdgcn_global_load_lds(
+                        (const __attribute__((address_space(1))) void *)(rowbase + off[j]),
+                        (__attribute__((address_space(3))) void *)(lds + (rr * CPB + j) * 1024), 16, 0, NT ? 2 : 0);
+            }
+            __syncthreads();                        // drains vmcnt: the phase has landed
+#pragma unroll
+            for (int rr = 0; rr < RPP; ++rr) {
+                const int ir = ph * RPP + rr, r = ir / BS, a = ir % BS;
+                if (a == 0) {
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) acc[c] = 0.f;
+                }
+#pragma unroll
+                for (int q = 0; q < CPB; ++q) {
+                    const f32x4 t = *reinterpret_cast<const f32x4 *>(lds + rr * CPB * 1024 + ((CPB * lane + (q ^ gq)) << 4));
+                    const float e[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+                    for (int s2 = 0; s2 < 4; ++s2) acc[(q * 4 + s2) / BS] += e[s2];
+                }
+                if (a == BS - 1) {
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        v[r * 8 + c] = acc[c] * (1.0f / (BS * BS));
+                        // pin the pooled value here: without it hipcc sinks all the adds below the last
+                        // phase and keeps every raw chunk live (178 VGPRs, 2 waves/SIMD)
+                        asm volatile("" : "+v"(v[r * 8 + c]) : : "memory");
+                    }
+                }
+            }
+        }
+        __syncthreads();                            // the staging buffer becomes the output tile
     } else {
         // SubSampling.execute fused (pipeline/subsampling.py:9-11): BS x BS mean, exact in fp32
         // for 8-bit samples (sum < 2^24, 1/BS^2 a power of two).
@@ -195,7 +263,10 @@ __global__ __launch_bounds__(64) void k_forward_fused(const float *__restrict__ 
                 }
             }
 #pragma unroll
-            for (int c = 0; c < 8; ++c) v[r * 8 + c] = acc[c] * (1.0f / (BS * BS));
+            for (int c = 0; c < 8; ++c) {
+                v[r * 8 + c] = acc[c] * (1.0f / (BS * BS));
+                asm volatile("" : "+v"(v[r * 8 + c]) : : "memory");   // fold now, do not keep raw samples live
+            }
         }
     }
 
@@ -765,7 +836,7 @@ int fill_inverse_params(int mode, double param, QuantParams *qp)
     }
 }
 
-template <int BS, bool NT>
+template <int BS, bool NT, int STAGED = 0>
 int launch_forward(const float *d_in, int H, int W, ptrdiff_t pitch, const QuantParams &qp, unsigned flags,
                    int16_t *d_out, hipStream_t st)
 {
@@ -783,11 +854,11 @@ int launch_forward(const float *d_in, int H, int W, ptrdiff_t pitch, const Quant
         else
             hipLaunchKernelGGL((k_forward_fused_strip<0, NT>), grid, block, 0, st, d_in, (size_t)pitch, wb, nblk, qp, d_out, g_counters);
     } else if (dc_exact)
-        hipLaunchKernelGGL((k_forward_fused<3, BS, NT>), grid, block, 0, st, d_in, (size_t)pitch, wb, nblk, qp, d_out, g_counters);
+        hipLaunchKernelGGL((k_forward_fused<3, BS, NT, STAGED>), grid, block, 0, st, d_in, (size_t)pitch, wb, nblk, qp, d_out, g_counters);
     else if (pixel)
-        hipLaunchKernelGGL((k_forward_fused<1, BS, NT>), grid, block, 0, st, d_in, (size_t)pitch, wb, nblk, qp, d_out, g_counters);
+        hipLaunchKernelGGL((k_forward_fused<1, BS, NT, STAGED>), grid, block, 0, st, d_in, (size_t)pitch, wb, nblk, qp, d_out, g_counters);
     else
-        hipLaunchKernelGGL((k_forward_fused<0, BS, NT>), grid, block, 0, st, d_in, (size_t)pitch, wb, nblk, qp, d_out, g_counters);
+        hipLaunchKernelGGL((k_forward_fused<0, BS, NT, STAGED>), grid, block, 0, st, d_in, (size_t)pitch, wb, nblk, qp, d_out, g_counters);
     HIP_TRY(hipGetLastError());
     return JPEGX_OK;
 }
@@ -972,9 +1043,19 @@ int jpegx_forward_fused_pooled(const float *d_in, int H, int W, ptrdiff_t pitch,
     if (rc) return rc;
     if (flags & JPEGX_F_TUNE_SKIP_EXACT) qp.tune |= 1;
     hipStream_t st = (hipStream_t)stream;
-    // The pooled kernels read partial lines per instruction (16 B at a 32*bs-byte lane stride);
-    // nontemporal loads then refetch every line and lose 30-60 % (profiles/r01_ab_pooled.txt),
-    // so they always use the default cache policy.
+    // Pooled input: staged through LDS by default (whole-line nontemporal DMA).  The per-lane
+    // variant reads partial lines per instruction (16 B at a 32*bs-byte lane stride); nontemporal
+    // loads then refetch every line and lose 30-60 % (profiles/r01_ab_pooled.txt), so that variant
+    // always uses the default cache policy.
+    if (bs > 1 && !(flags & JPEGX_F_TUNE_NO_STRIP)) {
+        const bool nt = !(flags & JPEGX_F_TUNE_NO_NT);
+        const int rpp = (flags & JPEGX_F_TUNE_POOL_ROWS_LO) ? 1 : ((flags & JPEGX_F_TUNE_POOL_ROWS_HI) ? 4 : 2);   // experiment: rows per phase
+#define JPEGX_LF(BSV, RPPV) (nt ? launch_forward<BSV, true, RPPV>(d_in, H, W, pitch, qp, flags, d_out, st) \
+                                : launch_forward<BSV, false, RPPV>(d_in, H, W, pitch, qp, flags, d_out, st))
+        if (bs == 2) return rpp == 1 ? JPEGX_LF(2, 1) : (rpp == 4 ? JPEGX_LF(2, 4) : JPEGX_LF(2, 2));
+        return rpp == 4 ? JPEGX_LF(4, 2) : JPEGX_LF(4, 1);
+#undef JPEGX_LF
+    }
     if (bs == 2) return launch_forward<2, false>(d_in, H, W, pitch, qp, flags, d_out, st);
     if (bs == 4) return launch_forward<4, false>(d_in, H, W, pitch, qp, flags, d_out, st);
     if (flags & JPEGX_F_TUNE_NO_NT) return launch_forward<1, false>(d_in, H, W, pitch, qp, flags, d_out, st);

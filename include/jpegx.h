@@ -57,7 +57,9 @@ typedef enum jpegx_quant_mode {
 /* tuning switches (A/B measurements in one process; results are identical either way) */
 #define JPEGX_F_TUNE_NO_NT 0x100u /* use the default cache policy instead of nontemporal accesses */
 #define JPEGX_F_TUNE_SKIP_EXACT 0x400u /* TIMING ONLY: skip the float64 exact tier (output no longer bit-exact) */
-#define JPEGX_F_TUNE_NO_STRIP 0x200u /* forward: per-lane global loads instead of the LDS-DMA strip  */
+#define JPEGX_F_TUNE_POOL_ROWS_LO 0x1000u /* pooled forward: fewer input rows per LDS phase (experiment) */
+#define JPEGX_F_TUNE_POOL_ROWS_HI 0x2000u /* pooled forward: more input rows per LDS phase (experiment)  */
+#define JPEGX_F_TUNE_NO_STRIP 0x200u /* forward: per-lane global loads instead of LDS-DMA staging    */
 
 /* output element type of jpegx_inverse_fused */
 typedef enum jpegx_out_type {
