@@ -493,6 +493,113 @@ __global__ __launch_bounds__(64) void k_forward_fused_strip(const float *__restr
 }
 
 // ------------------------------------------------------------------------------------------------
+// fused forward, ONE WAVEFRONT PER BLOCK (the layout sketched in BASELINE.json's north_star):
+// lane = one coefficient, the strip staged in LDS, both 1-D passes as 8 per-lane FMAs fed by
+// ds_bpermute (__shfl) from the 8 lanes of the row / column, quantise + zigzag scatter into the
+// LDS tile.  Kept as a selectable variant (JPEGX_F_TUNE_WAVE_PER_BLOCK) so that the choice of
+// the lane-per-block kernel above rests on a measurement (profiles/r01_ab_wave_per_block.txt),
+// not on an estimate: it needs 16 cross-lane fetches + 16 FMAs per BLOCK where lane-per-block
+// spends ~9 VALU instructions per block and no cross-lane traffic.  Results are identical.
+// The fp32 dots here are plain 8-term FMA chains (<= 9 roundings per pass), so the error
+// bound is scaled by 1.5 (24 u S) to stay rigorous.
+// ------------------------------------------------------------------------------------------------
+__device__ const float c_dct32[64] = {JPEGX_TABLE_DCT_MATRIX};   // fp32 roundings of C[k][n]
+
+constexpr int WPB_LDS_BYTES = STRIP_BYTES + TILE_BYTES + SCRATCH_DOUBLES * 8;
+
+template <int VAR, bool NT>
+__global__ __launch_bounds__(64) void k_forward_fused_wpb(const float *__restrict__ in, size_t pitch, int wb,
+                                                          int nblk, QuantParams prm, int16_t *__restrict__ out,
+                                                          unsigned long long *counters)
+{
+    constexpr bool PIXEL = (VAR & 1) != 0;
+    constexpr bool DC_EXACT = (VAR & 2) != 0;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[WPB_LDS_BYTES];
+    unsigned char *tile = lds + STRIP_BYTES;
+    double *sA = reinterpret_cast<double *>(lds + STRIP_BYTES + TILE_BYTES);
+    double *sM = sA + 64;
+
+    const int lane = threadIdx.x;
+    const int g0 = blockIdx.x * 64;
+    const int nvalid = min(64, nblk - g0);
+    {
+        const float *src[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int c = strip_swz(64 * j + lane);
+            const int gb = min(g0 + (c >> 1), nblk - 1);
+            const int by = gb / wb, bx = gb - by * wb;
+            src[j] = in + (size_t)by * 8 * pitch + (size_t)bx * 8 + (c & 1) * 4;
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src[0] + (size_t)r * pitch),
+                                             (__attribute__((address_space(3))) void *)(lds + r * 2048), 16, 0, NT ? 2 : 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src[1] + (size_t)r * pitch),
+                                             (__attribute__((address_space(3))) void *)(lds + r * 2048 + 1024), 16, 0, NT ? 2 : 0);
+        }
+    }
+    const int hi = lane >> 3, lo = lane & 7;
+    float crow[8], ccol[8];                     // C[l][0..7] for the row pass, C[k][0..7] for the column pass
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+        crow[n] = c_dct32[lo * 8 + n];
+        ccol[n] = c_dct32[hi * 8 + n];
+    }
+    float rq = 0.f;
+#pragma unroll
+    for (int n = 0; n < 64; ++n) rq = (lane == n) ? prm.rq32[n] : rq;   // kernarg SGPRs -> this lane's reciprocal
+    const int pz = c_zzinv.v[lane];
+    __syncthreads();                            // the strip has landed
+
+    unsigned nexact = 0;
+    for (int b = 0; b < nvalid; ++b) {
+        const int fb = ((b >> 2) ^ (b >> 3)) & 1;
+        const float x = *reinterpret_cast<const float *>(lds + hi * 2048 + ((2 * b + ((lo >> 2) ^ fb)) << 4) + (lo & 3) * 4);
+        float m = 0.f;                          // row pass: lane (i, l) = sum_n C[l][n] x[i][n]
+#pragma unroll
+        for (int n = 0; n < 8; ++n) m = fmaf(crow[n], __shfl(x, (lane & 56) | n), m);
+        float y = 0.f;                          // column pass: lane (k, l) = sum_i C[k][i] m[i][l]
+#pragma unroll
+        for (int i = 0; i < 8; ++i) y = fmaf(ccol[i], __shfl(m, (i << 3) | lo), y);
+        float S;
+        if (PIXEL) {
+            S = __shfl(y, 0);                   // DC = sum of the (non-negative) samples
+        } else {
+            S = fabsf(x);
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) S += __shfl_xor(S, d);
+        }
+        const float E = 1.5f * jpegx_fwd_err_bound(S);
+        const float t = y * rq;
+        float r = rintf(t);
+        bool unsafe = !(fmaf(E, rq, fabsf(t - r)) < 0.5f);
+        if (DC_EXACT && lane == 0) unsafe = false;
+        bool any = __any(unsafe) != 0;
+        if (prm.tune & 1) any = false;
+        if (any) {                              // exact tier: already in the one-wave-per-block layout
+            const double yd = coop_fwd_exact((double)x, sA, sM, lane);
+            r = (float)jpegx_clamp_i16(jpegx_quant_ref(yd, lane, prm.mode, prm.param, c_rq64.v));
+            ++nexact;
+        }
+        const int q = PIXEL ? (int)r : min(max((int)r, -32768), 32767);
+        *reinterpret_cast<int16_t *>(tile + tile_off(b, pz >> 3) + (pz & 7) * 2) = (int16_t)q;
+    }
+    if (counters != nullptr && lane == 0) {
+        atomicAdd(&counters[0], (unsigned long long)nexact);
+        atomicAdd(&counters[1], (unsigned long long)nvalid);
+    }
+    __syncthreads();
+    unsigned char *dst = reinterpret_cast<unsigned char *>(out) + (size_t)g0 * 128;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int row = i * 8 + (lane >> 3), c = lane & 7;
+        const u32x4 q4 = *reinterpret_cast<const u32x4 *>(tile + tile_off(row, c));
+        if (row < nvalid) st_u32x4<NT>(dst + (size_t)row * 128 + c * 16, q4);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // fused inverse: un-zigzag + dequantise + IDCT + round (+ clamp).  OUT: 0 f32, 1 i16, 2 u8.
 // ------------------------------------------------------------------------------------------------
 template <int OUT, bool NT>
@@ -846,7 +953,14 @@ int launch_forward(const float *d_in, int H, int W, ptrdiff_t pitch, const Quant
     // DC is an exact integer multiple of 2^-8 and rq[0] a power of two -> DC/q needs no tie check
     const bool dc_exact = pixel && is_pow2_float(qp.rq32[0]) &&
                           (qp.mode != JPEGX_Q_DIVIDE || (double)qp.rq32[0] * qp.param == 1.0);
-    if (BS == 1 && !(flags & JPEGX_F_TUNE_NO_STRIP)) {
+    if (BS == 1 && (flags & JPEGX_F_TUNE_WAVE_PER_BLOCK)) {
+        if (dc_exact)
+            hipLaunchKernelGGL((k_forward_fused_wpb<3, NT>), grid, block, 0, st, d_in, (size_t)pitch, wb, nblk, qp, d_out, g_counters);
+        else if (pixel)
+            hipLaunchKernelGGL((k_forward_fused_wpb<1, NT>), grid, block, 0, st, d_in, (size_t)pitch, wb, nblk, qp, d_out, g_counters);
+        else
+            hipLaunchKernelGGL((k_forward_fused_wpb<0, NT>), grid, block, 0, st, d_in, (size_t)pitch, wb, nblk, qp, d_out, g_counters);
+    } else if (BS == 1 && !(flags & JPEGX_F_TUNE_NO_STRIP)) {
         if (dc_exact)
             hipLaunchKernelGGL((k_forward_fused_strip<3, NT>), grid, block, 0, st, d_in, (size_t)pitch, wb, nblk, qp, d_out, g_counters);
         else if (pixel)

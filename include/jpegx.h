@@ -57,6 +57,8 @@ typedef enum jpegx_quant_mode {
 /* tuning switches (A/B measurements in one process; results are identical either way) */
 #define JPEGX_F_TUNE_NO_NT 0x100u /* use the default cache policy instead of nontemporal accesses */
 #define JPEGX_F_TUNE_SKIP_EXACT 0x400u /* TIMING ONLY: skip the float64 exact tier (output no longer bit-exact) */
+#define JPEGX_F_TUNE_WAVE_PER_BLOCK 0x800u /* forward: one-wavefront-per-block kernel (lane = coefficient,   \
+                                              ds_bpermute 1-D passes) instead of lane-per-block; same output */
 #define JPEGX_F_TUNE_POOL_ROWS_LO 0x1000u /* pooled forward: fewer input rows per LDS phase (experiment) */
 #define JPEGX_F_TUNE_POOL_ROWS_HI 0x2000u /* pooled forward: more input rows per LDS phase (experiment)  */
 #define JPEGX_F_TUNE_NO_STRIP 0x200u /* forward: per-lane global loads instead of LDS-DMA staging    */
