@@ -604,8 +604,9 @@ __global__ __launch_bounds__(64) void k_forward_fused_wpb(const float *__restric
 // ------------------------------------------------------------------------------------------------
 template <int OUT, bool NT>
 __global__ __launch_bounds__(64) void k_inverse_fused(const int16_t *__restrict__ in, int wb, int nblk,
-                                                      QuantParams prm, int clamp, void *__restrict__ outv,
-                                                      size_t opitch, unsigned long long *counters)
+                                                      QuantParams prm, int clamp, int inflate,
+                                                      void *__restrict__ outv, size_t opitch,
+                                                      unsigned long long *counters)
 {
     // f32 output is staged through an 8-row x 2 KiB strip (coalesced 1 KiB stores); the narrower
     // i16 / u8 rows are already contiguous per store instruction and go out directly.
@@ -742,16 +743,34 @@ __global__ __launch_bounds__(64) void k_inverse_fused(const int16_t *__restrict_
             st_u32x4<NT>(o + (size_t)r * opitch, u32x4{w[0], w[1], w[2], w[3]});
         }
     } else {
-        unsigned char *o = reinterpret_cast<unsigned char *>(outv) + (size_t)by * 8 * opitch + (size_t)bx * 8;
+        // uint8 rows, optionally with SubSampling.invert fused (util.inflate, util.py:6-14): every
+        // sample is replicated inflate x inflate times, the output plane is [H*inflate][W*inflate].
+        unsigned char *o = reinterpret_cast<unsigned char *>(outv) + (size_t)by * 8 * inflate * opitch + (size_t)bx * 8 * inflate;
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
-            unsigned w[2] = {0, 0};
+            unsigned u[8];
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const unsigned u = (unsigned)fminf(fmaxf(v[r * 8 + c], 0.f), 255.f);
-                w[c >> 2] |= u << (8 * (c & 3));
+            for (int c = 0; c < 8; ++c) u[c] = (unsigned)fminf(fmaxf(v[r * 8 + c], 0.f), 255.f);
+            if (inflate == 1) {
+                st_u32x2<NT>(o + (size_t)r * opitch, u32x2{u[0] | (u[1] << 8) | (u[2] << 16) | (u[3] << 24),
+                                                            u[4] | (u[5] << 8) | (u[6] << 16) | (u[7] << 24)});
+            } else if (inflate == 2) {
+                u32x4 w;
+                w.x = (u[0] * 0x0101u) | ((u[1] * 0x0101u) << 16);
+                w.y = (u[2] * 0x0101u) | ((u[3] * 0x0101u) << 16);
+                w.z = (u[4] * 0x0101u) | ((u[5] * 0x0101u) << 16);
+                w.w = (u[6] * 0x0101u) | ((u[7] * 0x0101u) << 16);
+                st_u32x4<NT>(o + (size_t)(2 * r) * opitch, w);
+                st_u32x4<NT>(o + (size_t)(2 * r + 1) * opitch, w);
+            } else {
+                const u32x4 w0 = {u[0] * 0x01010101u, u[1] * 0x01010101u, u[2] * 0x01010101u, u[3] * 0x01010101u};
+                const u32x4 w1 = {u[4] * 0x01010101u, u[5] * 0x01010101u, u[6] * 0x01010101u, u[7] * 0x01010101u};
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    st_u32x4<NT>(o + (size_t)(4 * r + a) * opitch, w0);
+                    st_u32x4<NT>(o + (size_t)(4 * r + a) * opitch + 16, w1);
+                }
             }
-            st_u32x2<NT>(o + (size_t)r * opitch, u32x2{w[0], w[1]});
         }
     }
 }
@@ -1182,15 +1201,16 @@ int jpegx_forward_fused(const float *d_in, int H, int W, ptrdiff_t pitch, int mo
     return jpegx_forward_fused_pooled(d_in, H, W, pitch, 1, mode, param, flags, d_out, stream);
 }
 
-int jpegx_inverse_fused(const int16_t *d_in, int H, int W, int mode, double param, unsigned flags, void *d_out,
-                        ptrdiff_t out_pitch, int out_type, jpegx_stream_t stream)
+static int inverse_common(const int16_t *d_in, int H, int W, int mode, double param, unsigned flags, void *d_out,
+                          ptrdiff_t out_pitch, int out_type, int inflate, jpegx_stream_t stream)
 {
-    int rc = check_plane(d_in, d_out, H, W, out_pitch, 1);
+    int rc = check_plane(d_in, d_out, H, W, out_pitch / inflate, 1);
     if (rc) return rc;
+    if (out_pitch < (ptrdiff_t)W * inflate) return fail(JPEGX_E_INVALID, "output pitch smaller than the inflated width");
     const int esz = out_type == JPEGX_OUT_F32 ? 4 : (out_type == JPEGX_OUT_I16 ? 2 : 1);
     if (out_type < 0 || out_type > 2) return fail(JPEGX_E_INVALID, "unknown output type");
-    if (((size_t)out_pitch * esz) % (esz == 1 ? 8 : 16) != 0 || !aligned16(d_in) || !aligned16(d_out))
-        return fail(JPEGX_E_INVALID, "inverse: output rows must stay 16-byte (u8: 8-byte) aligned");
+    if (((size_t)out_pitch * esz) % ((esz == 1 && inflate == 1) ? 8 : 16) != 0 || !aligned16(d_in) || !aligned16(d_out))
+        return fail(JPEGX_E_INVALID, "inverse: output rows must stay 16-byte (plain u8: 8-byte) aligned");
     QuantParams qp;
     rc = fill_inverse_params(mode, param, &qp);
     if (rc) return rc;
@@ -1201,13 +1221,26 @@ int jpegx_inverse_fused(const int16_t *d_in, int H, int W, int mode, double para
     hipStream_t st = (hipStream_t)stream;
     const bool nt = (flags & JPEGX_F_TUNE_NO_NT) == 0;
 #define JPEGX_LAUNCH_INV(OUT, NT, CL) \
-    hipLaunchKernelGGL((k_inverse_fused<OUT, NT>), grid, block, 0, st, d_in, wb, nblk, qp, CL, d_out, (size_t)out_pitch, g_counters)
+    hipLaunchKernelGGL((k_inverse_fused<OUT, NT>), grid, block, 0, st, d_in, wb, nblk, qp, CL, inflate, d_out, (size_t)out_pitch, g_counters)
     if (out_type == JPEGX_OUT_F32) { if (nt) JPEGX_LAUNCH_INV(0, true, clamp); else JPEGX_LAUNCH_INV(0, false, clamp); }
     else if (out_type == JPEGX_OUT_I16) { if (nt) JPEGX_LAUNCH_INV(1, true, clamp); else JPEGX_LAUNCH_INV(1, false, clamp); }
     else { if (nt) JPEGX_LAUNCH_INV(2, true, 1); else JPEGX_LAUNCH_INV(2, false, 1); }
 #undef JPEGX_LAUNCH_INV
     HIP_TRY(hipGetLastError());
     return JPEGX_OK;
+}
+
+int jpegx_inverse_fused(const int16_t *d_in, int H, int W, int mode, double param, unsigned flags, void *d_out,
+                        ptrdiff_t out_pitch, int out_type, jpegx_stream_t stream)
+{
+    return inverse_common(d_in, H, W, mode, param, flags, d_out, out_pitch, out_type, 1, stream);
+}
+
+int jpegx_inverse_fused_u8_inflated(const int16_t *d_in, int H, int W, int mode, double param, unsigned flags, int bs,
+                                    uint8_t *d_out, ptrdiff_t out_pitch, jpegx_stream_t stream)
+{
+    if (bs != 1 && bs != 2 && bs != 4) return fail(JPEGX_E_UNSUPPORTED, "fused inflate supports block_size 1, 2 and 4");
+    return inverse_common(d_in, H, W, mode, param, flags, d_out, out_pitch, JPEGX_OUT_U8, bs, stream);
 }
 
 int jpegx_dct8x8_f32(const float *d_in, int H, int W, ptrdiff_t pitch, float *d_out, ptrdiff_t out_pitch,

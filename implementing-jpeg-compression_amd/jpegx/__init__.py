@@ -67,6 +67,7 @@ SIGNATURES = {
     "jpegx_forward_fused": [_vp, _int, _int, _pd, _int, _dbl, _uint, _vp, _vp],
     "jpegx_forward_fused_pooled": [_vp, _int, _int, _pd, _int, _int, _dbl, _uint, _vp, _vp],
     "jpegx_inverse_fused": [_vp, _int, _int, _int, _dbl, _uint, _vp, _pd, _int, _vp],
+    "jpegx_inverse_fused_u8_inflated": [_vp, _int, _int, _int, _dbl, _uint, _int, _vp, _pd, _vp],
     "jpegx_dct8x8_f32": [_vp, _int, _int, _pd, _vp, _pd, _vp],
     "jpegx_idct8x8_f32": [_vp, _int, _int, _pd, _vp, _pd, _vp],
     "jpegx_dct8x8_f64": [_vp, _int, _int, _pd, _vp, _pd, _vp],
@@ -292,6 +293,25 @@ def inverse_fused(zz, mode="qtable", param=0.0, out="f32", clamp=False):
                                          F_CLAMP_U8 if clamp else 0, res.ctypes.data, w, ot),
           "jpegx_host_inverse_fused")
     return res
+
+
+def inverse_fused_u8(zz, mode="qtable", param=0.0, inflate=1):
+    """int16 (H/8, W/8, 64) -> uint8 (H*inflate, W*inflate): fused inverse + clamp + SubSampling.invert."""
+    z = np.ascontiguousarray(zz, dtype=np.int16)
+    if z.ndim != 3 or z.shape[2] != 64:
+        raise JpegxError("expected a (H/8, W/8, 64) coefficient stream, got %r" % (z.shape,))
+    h, w = z.shape[0] * 8, z.shape[1] * 8
+    bs = int(inflate)
+    out = np.empty((h * bs, w * bs), dtype=np.uint8)
+    din, dout = DeviceBuffer(z.nbytes), DeviceBuffer(out.nbytes)
+    try:
+        din.upload(z)
+        check(lib().jpegx_inverse_fused_u8_inflated(din.ptr, h, w, mode_of(mode), float(param), 0, bs, dout.ptr,
+                                                    w * bs, None), "jpegx_inverse_fused_u8_inflated")
+        return dout.download(out.shape, np.uint8)
+    finally:
+        din.free()
+        dout.free()
 
 
 def dct8x8_f64(a):

@@ -113,10 +113,61 @@ def _hot_inverse(zz, config):
     return jpegx.idct8x8_f64(plane, do_round=True).astype(int)
 
 
+_HOT_STEPS = (basis_change.BasisChange, quantization.Quantization, zigzag_order.ZigzagOrder)
+_BUILTIN_STEPS = (padding.Padding, subsampling.SubSampling, dct_padding.DCTPadding, normalization.Normalization,
+                  basis_change.BasisChange, quantization.Quantization, zigzag_order.ZigzagOrder,
+                  run_length_encoding.RunLengthEncoding, rle_byte_stream.RleBytestream)
+
+
+def _stock_registry():
+    """True while nobody has registered extra steps: only then may whole groups of steps be fused."""
+    return len(step_classes) == len(_BUILTIN_STEPS) and all(a is b for a, b in zip(step_classes, _BUILTIN_STEPS))
+
+
+def _front_end_fused(band, config):
+    """Steps 0-6 in one launch when the band needs no DCT padding: Padding on the host (edge
+    replication to a multiple of block_size), then SubSampling + BasisChange + Quantization +
+    ZigzagOrder inside jpegx_forward_fused_pooled.  Returns None when not applicable."""
+    bs = config.block_size
+    band = np.asarray(band)
+    if bs not in (1, 2, 4) or band.ndim != 2 or band.size == 0 or band.dtype.kind not in "ui":
+        return None
+    if band.min() < 0 or band.max() > 255:
+        return None
+    padded = band if bs == 1 else padding.Padding(config).execute(band)
+    if padded.shape[0] % (8 * bs) or padded.shape[1] % (8 * bs):
+        return None
+    import jpegx
+    mode, param = config.quantization.gpu_mode()
+    return jpegx.forward_fused_pooled(padded.astype(np.float32), bs, mode, param, pixel_input=True).astype(np.float64)
+
+
+def _back_end_fused(zz, config):
+    """Steps 6-0 inverted in one launch: un-zigzag, dequantise, IDCT, round, clamp to [0, 255]
+    (Normalization.invert), replicate block_size x block_size (SubSampling.invert) on the GPU,
+    then the two crops (DCTPadding.invert, Padding.invert) as one slice."""
+    bs = config.block_size
+    zz = np.asarray(zz)
+    mode, param = config.quantization.gpu_mode()
+    if bs not in (1, 2, 4) or zz.ndim != 3 or zz.shape[2] != 64 or zz.size == 0:
+        return None
+    if np.abs(zz).max() > 32767 or not np.array_equal(zz, np.rint(zz)) or \
+            (mode == "divide" and abs(param) * 32767 >= 2 ** 24):
+        return None
+    import jpegx
+    full = jpegx.inverse_fused_u8(zz.astype(np.int16), mode, param, inflate=bs)
+    return full[:config.height, :config.width].astype(int)
+
+
 def compress_band(a, config):
     """Run every registered step forward (pipeline/__init__.py:71-76)."""
     fused = _accelerated(config)
-    for cls in step_classes:
+    todo = list(step_classes)
+    if fused and _stock_registry():
+        zz = _front_end_fused(a, config)
+        if zz is not None:
+            a, todo = zz, todo[7:]                    # steps 0-6 done in one launch
+    for cls in todo:
         if fused and cls.step_index in (5, 6) and cls in _HOT_STEPS:
             continue                                   # folded into the fused launch below
         if fused and cls is basis_change.BasisChange:
@@ -130,7 +181,15 @@ def decompress_band(compression_result, config):
     """Run every registered step backwards (pipeline/__init__.py:79-88)."""
     a = compression_result
     fused = _accelerated(config)
-    for cls in reversed(step_classes):
+    todo = list(reversed(step_classes))
+    if fused and _stock_registry():
+        for cls in todo[:2]:                           # entropy stage (steps 8, 7) on the host
+            a = cls(config).invert(a)
+        band = _back_end_fused(a, config)
+        if band is not None:
+            return band
+        todo = todo[2:]
+    for cls in todo:
         if fused and cls.step_index in (4, 5) and cls in _HOT_STEPS:
             continue
         if fused and cls is zigzag_order.ZigzagOrder:
@@ -138,9 +197,6 @@ def decompress_band(compression_result, config):
             continue
         a = cls(config).invert(a)
     return a
-
-
-_HOT_STEPS = (basis_change.BasisChange, quantization.Quantization, zigzag_order.ZigzagOrder)
 
 
 class CompressedData:

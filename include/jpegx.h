@@ -123,6 +123,13 @@ int jpegx_forward_fused_pooled(const float *d_in, int H, int W, ptrdiff_t pitch,
 int jpegx_inverse_fused(const int16_t *d_in, int H, int W, int mode, double param, unsigned flags,
                         void *d_out, ptrdiff_t out_pitch, int out_type, jpegx_stream_t stream);
 
+/* Inverse straight to displayable samples: uint8 with the clamp of pipeline/normalization.py:10-14
+ * AND SubSampling.invert (pipeline/subsampling.py:13-14 -> util.inflate, util.py:6-14) fused:
+ * every sample is replicated bs x bs times (bs in {1,2,4}); d_out is [H*bs][out_pitch >= W*bs]. */
+int jpegx_inverse_fused_u8_inflated(const int16_t *d_in, int H, int W, int mode, double param,
+                                    unsigned flags, int bs, uint8_t *d_out, ptrdiff_t out_pitch,
+                                    jpegx_stream_t stream);
+
 /* ---- unfused fp32 stage kernels (per-stage parity; coefficients within 1e-4 of the float64
  *      reference, normalised by the block maximum) ---------------------------------------- */
 /* DCT.transform_2d blockwise: transforms.py:46-58 via basis_change.py:15-18 */

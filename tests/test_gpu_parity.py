@@ -231,3 +231,15 @@ def test_exact_tier_census_counters(gpu):
     flagged, total = cnt.download((2,), np.uint64)
     assert total == (h // 8) * (w // 8)
     assert 0.01 < flagged / total < 0.08
+
+
+@pytest.mark.parametrize("bs", [1, 2, 4])
+def test_inverse_u8_with_fused_inflate(gpu, bs):
+    """Clamp + SubSampling.invert (util.inflate) fused into the inverse: equals np.repeat of the oracle."""
+    for h, w in ((64, 512), (24, 40)):
+        a = gpu.synth.generate_plane("noise", h, w, seed=9 + bs)
+        zz = oracle.forward_f32(a, "qtable")
+        want = np.clip(oracle.inverse_i16(zz, "qtable"), 0, 255).astype(np.uint8)
+        want = np.repeat(np.repeat(want, bs, axis=0), bs, axis=1)
+        got = gpu.inverse_fused_u8(zz, "qtable", inflate=bs)
+        assert got.shape == want.shape and np.array_equal(got, want)
