@@ -1048,6 +1048,9 @@ int host_roundtrip(const void *h_in, size_t in_bytes, void *h_out, size_t out_by
 
 extern "C" {
 
+// used by the other translation units of libjpegx.so (jpegx_entropy.hip); not part of the public ABI
+void jpegx_internal_set_error(const char *msg) { snprintf(g_err, sizeof(g_err), "%s", msg ? msg : ""); }
+
 const char *jpegx_last_error(void) { return g_err; }
 int jpegx_version(void) { return JPEGX_VERSION; }
 

@@ -87,7 +87,13 @@ SIGNATURES = {
     "jpegx_host_dct8x8_f32": [_vp, _int, _int, _vp],
     "jpegx_host_idct8x8_f32": [_vp, _int, _int, _vp],
     "jpegx_set_debug_counters": [_vp],
+    "jpegx_entropy_workspace_bytes": [_c.c_longlong],
+    "jpegx_entropy_sizes": [_vp, _c.c_longlong, _vp, _vp],
+    "jpegx_entropy_total": [_vp, _c.POINTER(_c.c_ulonglong), _vp],
+    "jpegx_entropy_emit": [_vp, _c.c_longlong, _vp, _vp, _vp],
+    "jpegx_host_entropy_encode": [_vp, _c.c_longlong, _vp, _sz, _c.POINTER(_sz)],
 }
+RESTYPES = {"jpegx_entropy_workspace_bytes": _sz}   # everything else returns int
 
 
 def lib():
@@ -108,7 +114,7 @@ def lib():
         for name, argtypes in SIGNATURES.items():
             fn = getattr(L, name)
             fn.argtypes = argtypes
-            fn.restype = ctypes.c_int
+            fn.restype = RESTYPES.get(name, ctypes.c_int)
         _lib = L
     return _lib
 
@@ -381,3 +387,47 @@ def idct8x8_f32(a):
     out = np.empty_like(a)
     check(lib().jpegx_host_idct8x8_f32(a.ctypes.data, a.shape[0], a.shape[1], out.ctypes.data), "jpegx_host_idct8x8_f32")
     return out
+
+
+def entropy_encode(zz):
+    """int16 (..., 64) zigzag stream -> bytes: RunLengthEncoding.execute + RleBytestream.execute on the GPU."""
+    z = np.ascontiguousarray(zz, dtype=np.int16)
+    if z.ndim < 1 or z.shape[-1] != 64 or z.size == 0:
+        raise JpegxError("expected a (..., 64) coefficient stream, got %r" % (z.shape,))
+    nblocks = z.size // 64
+    n = ctypes.c_size_t(0)
+    check(lib().jpegx_host_entropy_encode(z.ctypes.data, nblocks, None, 0, ctypes.byref(n)), "jpegx_host_entropy_encode")
+    out = np.empty(max(1, n.value), dtype=np.uint8)
+    check(lib().jpegx_host_entropy_encode(z.ctypes.data, nblocks, out.ctypes.data, out.size, ctypes.byref(n)),
+          "jpegx_host_entropy_encode")
+    return out[:n.value].tobytes()
+
+
+def compress_plane(plane, block_size=1, mode="qtable", param=0.0):
+    """Steps 1-8 of the codec for one (already padded) plane with everything on the device:
+    fused mean-pool + DCT + quantise + zigzag, then the entropy stage; only the final bytes come back."""
+    a = _plane(plane, np.float32)
+    bs = int(block_size)
+    hh, ww = a.shape
+    if hh % (8 * bs) or ww % (8 * bs):
+        raise JpegxError("plane must be a multiple of 8*block_size in both dimensions")
+    h, w = hh // bs, ww // bs
+    nblocks = (h // 8) * (w // 8)
+    L = lib()
+    din, dzz = DeviceBuffer(a.nbytes), DeviceBuffer(h * w * 2)
+    dws = DeviceBuffer(L.jpegx_entropy_workspace_bytes(nblocks))
+    dout = None
+    try:
+        din.upload(a)
+        forward_fused_device(din.ptr, h, w, dzz.ptr, mode, param, F_PIXEL_INPUT if is_pixel_like(a) else 0,
+                             pitch=ww, pool=bs)
+        check(L.jpegx_entropy_sizes(dzz.ptr, nblocks, dws.ptr, None), "jpegx_entropy_sizes")
+        total = ctypes.c_ulonglong(0)
+        check(L.jpegx_entropy_total(dws.ptr, ctypes.byref(total), None), "jpegx_entropy_total")
+        dout = DeviceBuffer(max(1, total.value))
+        check(L.jpegx_entropy_emit(dzz.ptr, nblocks, dws.ptr, dout.ptr, None), "jpegx_entropy_emit")
+        return dout.download((total.value,), np.uint8).tobytes()
+    finally:
+        for b in (din, dzz, dws, dout):
+            if b is not None:
+                b.free()

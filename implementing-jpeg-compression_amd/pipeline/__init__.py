@@ -124,10 +124,12 @@ def _stock_registry():
     return len(step_classes) == len(_BUILTIN_STEPS) and all(a is b for a, b in zip(step_classes, _BUILTIN_STEPS))
 
 
-def _front_end_fused(band, config):
-    """Steps 0-6 in one launch when the band needs no DCT padding: Padding on the host (edge
-    replication to a multiple of block_size), then SubSampling + BasisChange + Quantization +
-    ZigzagOrder inside jpegx_forward_fused_pooled.  Returns None when not applicable."""
+def _front_end_fused(band, config, with_entropy):
+    """Steps 0-6 (or 0-8 when with_entropy) on the GPU when the band needs no DCT padding: Padding
+    on the host (edge replication to a multiple of block_size), then SubSampling + BasisChange +
+    Quantization + ZigzagOrder inside jpegx_forward_fused_pooled, then optionally
+    RunLengthEncoding + RleBytestream (jpegx_entropy_*) with the coefficients never leaving the
+    device.  Returns None when not applicable."""
     bs = config.block_size
     band = np.asarray(band)
     if bs not in (1, 2, 4) or band.ndim != 2 or band.size == 0 or band.dtype.kind not in "ui":
@@ -139,6 +141,8 @@ def _front_end_fused(band, config):
         return None
     import jpegx
     mode, param = config.quantization.gpu_mode()
+    if with_entropy:
+        return jpegx.compress_plane(padded.astype(np.float32), bs, mode, param)
     return jpegx.forward_fused_pooled(padded.astype(np.float32), bs, mode, param, pixel_input=True).astype(np.float64)
 
 
@@ -164,9 +168,9 @@ def compress_band(a, config):
     fused = _accelerated(config)
     todo = list(step_classes)
     if fused and _stock_registry():
-        zz = _front_end_fused(a, config)
-        if zz is not None:
-            a, todo = zz, todo[7:]                    # steps 0-6 done in one launch
+        blob = _front_end_fused(a, config, with_entropy=True)
+        if blob is not None:
+            return blob                               # all nine steps on the device
     for cls in todo:
         if fused and cls.step_index in (5, 6) and cls in _HOT_STEPS:
             continue                                   # folded into the fused launch below

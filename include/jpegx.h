@@ -158,6 +158,23 @@ int jpegx_zigzag(const void *d_in, int H, int W, ptrdiff_t pitch, int elem_size,
 int jpegx_unzigzag(const void *d_in, int H, int W, int elem_size, void *d_out, ptrdiff_t out_pitch,
                    jpegx_stream_t stream);
 
+/* ---- entropy stage on the device ---------------------------------------
+ * Replaces RunLengthEncoding.execute (pipeline/run_length_encoding.py:47-64) + RleBytestream.execute
+ * (pipeline/rle_byte_stream.py:48-59) for dct_size 8: int16 zigzag stream of `nblocks` blocks ->
+ * the reference's byte stream (4-bit run, 4-bit size, sign + magnitude bits, 15-zero chain codes,
+ * EOB byte, per-block byte alignment).  Usage: jpegx_entropy_sizes (enqueue: per-block sizes and
+ * byte offsets into the workspace) -> jpegx_entropy_total (synchronises, returns the total and
+ * JPEGX_E_INVALID if an amplitude exceeds 15 bits, the reference's BadRleCodeError) ->
+ * jpegx_entropy_emit into a buffer of at least `total` bytes.                                  */
+size_t jpegx_entropy_workspace_bytes(long long nblocks);
+int jpegx_entropy_sizes(const int16_t *d_zz, long long nblocks, void *d_workspace, jpegx_stream_t stream);
+int jpegx_entropy_total(const void *d_workspace, unsigned long long *h_total, jpegx_stream_t stream);
+int jpegx_entropy_emit(const int16_t *d_zz, long long nblocks, const void *d_workspace, uint8_t *d_out,
+                       jpegx_stream_t stream);
+/* host convenience; h_out may be NULL to query the size only */
+int jpegx_host_entropy_encode(const int16_t *h_zz, long long nblocks, uint8_t *h_out, size_t cap,
+                              size_t *nbytes);
+
 /* ---- synchronous host-pointer conveniences (H2D, kernel, D2H on an internal stream) ------ */
 int jpegx_host_forward_fused(const float *h_in, int H, int W, ptrdiff_t pitch, int mode,
                              double param, unsigned flags, int16_t *h_out);

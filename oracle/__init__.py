@@ -53,6 +53,11 @@ def lib():
         L.jo_inverse_i16.argtypes = [ctypes.POINTER(ctypes.c_int16), c_int, c_int, c_int, c_dbl,
                                      ctypes.POINTER(ctypes.c_int32), dp]
         L.jo_mean_pool.argtypes = [dp, c_int, c_int, c_int, dp]
+        L.jo_rle_block_tuples.argtypes = [ctypes.POINTER(ctypes.c_int16), c_int, ctypes.POINTER(c_int)]
+        L.jo_rle_bytestream.argtypes = [ctypes.POINTER(ctypes.c_int16), ctypes.c_longlong, c_int,
+                                        ctypes.POINTER(ctypes.c_uint8), ctypes.c_longlong,
+                                        ctypes.POINTER(ctypes.c_uint32)]
+        L.jo_rle_bytestream.restype = ctypes.c_longlong
         for n in ("jo_table_dct_matrix", "jo_table_dct_normalized", "jo_table_norm_diag"):
             getattr(L, n).restype = dp
         for n in ("jo_table_qtable", "jo_table_zigzag"):
@@ -176,3 +181,31 @@ def mean_pool(a, bs):
     out = np.empty((h // bs, w // bs), dtype=np.float64)
     _check(lib().jo_mean_pool(_p(a, ctypes.c_double), h, w, int(bs), _p(out, ctypes.c_double)), "mean_pool")
     return out
+
+
+def rle_block_tuples(values):
+    """RunLengthBlock.encode + as_tuple for one block (pipeline/run_length_encoding.py:14-32); EOB -> (0, 0)."""
+    z = np.ascontiguousarray(values, dtype=np.int16).reshape(-1)
+    buf = np.zeros(3 * (2 * z.size + 2), dtype=np.int32)
+    k = lib().jo_rle_block_tuples(_p(z, ctypes.c_int16), z.size, _p(buf, ctypes.c_int))
+    if k < 0:
+        raise ValueError("amplitude needs more than 15 bits")
+    out = []
+    for r, s_, a in buf[:3 * k].reshape(k, 3).tolist():
+        out.append((0, 0) if (r == 0 and s_ == 0) else (r, s_, a))
+    return out
+
+
+def rle_bytestream(zz, want_block_bytes=False):
+    """Steps 7+8 (RunLengthEncoding.execute + RleBytestream.execute) on an integer (..., n) zigzag stream."""
+    z = np.ascontiguousarray(zz, dtype=np.int16)
+    n = z.shape[-1]
+    nblocks = z.size // n
+    sizes = np.zeros(nblocks, dtype=np.uint32)
+    total = lib().jo_rle_bytestream(_p(z, ctypes.c_int16), nblocks, n, None, 0, _p(sizes, ctypes.c_uint32))
+    if total < 0:
+        raise ValueError("amplitude needs more than 15 bits")
+    out = np.zeros(total, dtype=np.uint8)
+    got = lib().jo_rle_bytestream(_p(z, ctypes.c_int16), nblocks, n, _p(out, ctypes.c_uint8), total, None)
+    assert got == total
+    return (out.tobytes(), sizes) if want_block_bytes else out.tobytes()

@@ -1,0 +1,60 @@
+"""GPU: the entropy stage (steps 7+8) on the device against the oracle's restatement, which is
+pinned by the reference's own known answers (tests/test_oracle_golden.py)."""
+import numpy as np
+import pytest
+
+import oracle
+from conftest import CASES, MODES
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("suffix,mode,param", MODES)
+def test_entropy_encode_matches_oracle_on_reference_streams(gpu, golden, case, suffix, mode, param):
+    zz = golden(case)["zz_" + suffix]
+    assert gpu.entropy_encode(zz) == oracle.rle_bytestream(zz)
+
+
+def test_entropy_encode_known_answers(gpu):
+    """/root/reference/tests/RLE_tests.py:98-122 restated on 64-value blocks."""
+    def bits(b):
+        return "".join(format(x, "08b") for x in b)
+    z = np.zeros((1, 64), np.int16)
+    z[0, 4] = 2
+    assert bits(gpu.entropy_encode(z)) == "0100" + "0011" + "110" + "0" * 13
+    z = np.zeros((1, 64), np.int16)
+    z[0, 15] = 1
+    z[0, 63] = -3                                    # run 47 = 3 chains + 2
+    want = "11110000" + "0000" "0010" "11" + "11110000" * 3 + "0010" "0011" "011" + "0" * 8
+    got = bits(gpu.entropy_encode(z))
+    assert got.startswith(want) and len(got) % 8 == 0 and set(got[len(want):]) <= {"0"}
+    assert gpu.entropy_encode(np.zeros((3, 64), np.int16)) == b"\x00\x00\x00"
+
+
+@pytest.mark.parametrize("kind", ["noise", "smooth"])
+def test_entropy_encode_large_and_ragged(gpu, kind):
+    a = gpu.synth.generate_plane(kind, 1024, 1024, seed=13)
+    for mode, param in (("qtable", 0.0), ("none", 0.0), ("divide", 7.0)):
+        zz = oracle.forward_f32(a, mode, param)
+        assert gpu.entropy_encode(zz) == oracle.rle_bytestream(zz)
+    rng = np.random.default_rng(2)
+    for nblocks in (1, 63, 64, 65, 1000):
+        z = (rng.integers(-40, 41, (nblocks, 64)) * (rng.random((nblocks, 64)) < 0.2)).astype(np.int16)
+        z[0, :] = rng.integers(-16383, 16384, 64)     # dense block with maximal amplitudes
+        assert gpu.entropy_encode(z) == oracle.rle_bytestream(z)
+
+
+def test_entropy_rejects_amplitudes_beyond_15_bits(gpu):
+    z = np.zeros((2, 64), np.int16)
+    z[1, 3] = 16384
+    with pytest.raises(gpu.JpegxError, match="15 bits"):
+        gpu.entropy_encode(z)
+
+
+def test_compress_plane_all_on_device(gpu):
+    """Steps 1-8 with only the final bytes leaving the GPU == oracle forward + oracle entropy stage."""
+    a = gpu.synth.generate_plane("smooth", 256, 512, seed=6)
+    assert gpu.compress_plane(a, 1, "qtable") == oracle.rle_bytestream(oracle.forward_f32(a, "qtable"))
+    pooled = oracle.mean_pool(a, 2).astype(np.float32)
+    assert gpu.compress_plane(a, 2, "qtable") == oracle.rle_bytestream(oracle.forward_f32(pooled, "qtable"))

@@ -84,3 +84,45 @@ def test_python_loop_restatement_agrees(golden):
 def test_bad_shapes_are_rejected():
     with pytest.raises(ValueError):
         oracle.dct_plane(np.zeros((12, 8)))
+
+
+# ---- entropy stage (steps 7-8): pinned by the reference's own known answers -------------------
+def test_rle_tuples_known_answers():
+    """/root/reference/tests/RLE_tests.py:16-64."""
+    assert oracle.rle_block_tuples([-15, 0, 0, 0, 3, 2, 0, 0, 0, 0, 120, 0, 0, 0, 0]) == \
+        [(0, 5, -15), (3, 3, 3), (0, 3, 2), (4, 8, 120), (0, 0)]
+    assert oracle.rle_block_tuples([0, 2] + [0] * 32 + [5] + [0] * 5) == \
+        [(1, 3, 2), (15, 0, 0), (15, 0, 0), (2, 4, 5), (0, 0)]
+    assert oracle.rle_block_tuples([0] * 9) == [(0, 0)]
+    # step level, tests/RLE_tests.py:66-86
+    blocks = [[21, 3, 0, 0, 0, 0, 2, 0, 0], [0, 0, 0, 15, 0, 0, 0, 0, 9], [0] * 9]
+    got = [t for b in blocks for t in oracle.rle_block_tuples(b)]
+    assert got == [(0, 6, 21), (0, 3, 3), (4, 3, 2), (0, 0), (3, 5, 15), (4, 5, 9), (0, 0), (0, 0)]
+
+
+def test_rle_bytestream_known_bit_strings():
+    """/root/reference/tests/RLE_tests.py:98-122: '0100 0011 110' + padding, '1111 0000' + EOB."""
+    def bits(b):
+        return "".join(format(x, "08b") for x in b)
+    assert bits(oracle.rle_bytestream(np.array([[0, 0, 0, 0, 2, 0, 0, 0, 0]]))) == "0100" + "0011" + "110" + "0" * 13
+    # a value after 15 zeros: (15,0,0) then (0, size, amp): '11110000' + '0000' '0010' '11' + pad + EOB
+    z = np.zeros((1, 20), np.int16)
+    z[0, 15] = 1
+    assert bits(oracle.rle_bytestream(z)).startswith("11110000" + "0000" + "0010" + "11")
+    assert bits(oracle.rle_bytestream(np.zeros((2, 9), np.int16))) == "0" * 16
+    # negative amplitudes: sign bit 0 (tests/RLE_tests.py:132-139 round-trip codes)
+    z = np.zeros((1, 4), np.int16)
+    z[0, 1] = -1
+    assert bits(oracle.rle_bytestream(z)).startswith("0001" + "0010" + "01")
+
+
+def test_rle_bytestream_matches_the_host_mirror(golden):
+    """The pure-Python mirror of steps 7-8 (product host code) and the oracle agree on real streams."""
+    from pipeline.rle_byte_stream import RleBytestream
+    from pipeline.run_length_encoding import RunLengthEncoding
+    c = golden("smooth64")
+    for suffix, _, _ in MODES:
+        zz = c["zz_" + suffix]
+        want = RleBytestream(None).execute(RunLengthEncoding(None).execute(zz.astype(float)))
+        blob, sizes = oracle.rle_bytestream(zz, want_block_bytes=True)
+        assert blob == want and int(sizes.sum()) == len(blob)
