@@ -8,11 +8,14 @@
 //   byte boundary, so blocks are independent byte strings that are simply concatenated.
 //
 // Three launches (all enqueue-only):
-//   k_rle_sizes   lane-per-block (same LDS-DMA tile staging as the inverse kernel): bytes per block,
+//   k_rle_sizes   lane-per-block (same LDS-DMA tile staging as the inverse kernel): a 64-bit
+//                 non-zero mask per block, then a walk over the set bits only; bytes per block
 //                 plus the wave's total by a cross-lane sum;
-//   k_scan_waves  one workgroup: exclusive scan of the wave totals -> 64-bit byte offset per wave;
-//   k_rle_emit    lane-per-block again: in-wave exclusive scan of the block sizes, then every lane
-//                 packs its block MSB-first through a 64-bit accumulator and writes its bytes.
+//   k_scan_level1/2  exclusive scan of the wave totals (chunked) -> byte offset of every wave;
+//   k_rle_emit    lane-per-block again: in-wave exclusive scan of the block sizes, every lane packs
+//                 its block MSB-first through a 64-bit accumulator into an LDS staging area laid
+//                 out at the destination's offset modulo 16, and the wave copies the contiguous
+//                 span out with aligned 16-byte stores (bytes only at the two ends).
 // Blocks are independent, so this shards over GPUs exactly like the transform (jpegx/multigpu.py).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -29,29 +32,36 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr int TILE_BYTES = 64 * 128;
 __device__ __forceinline__ int tile_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
 
-// workspace layout (bytes): [0,8) total, [8,12) error flag, [16, 16+8(nw+1)) wave offsets (u64),
-// then wave totals (u32 x nw, 8-byte aligned), then block sizes (u32 x nblocks)
+// workspace layout (bytes): [0,8) total, [8,12) error flag, [16, ...) 64-bit byte offset of every
+// scan chunk (SCAN_CHUNK waves), then per wave its total and its 32-bit offset inside the chunk
+// (both 16-byte aligned arrays), then block sizes (u32 x nblocks)
+constexpr int SCAN_CHUNK = 4096;   // waves per level-1 scan workgroup (1024 threads x 4)
+
 struct Workspace {
     unsigned long long *total;
     unsigned *error;
-    unsigned long long *wave_off;
-    unsigned *wave_bytes;
-    unsigned *block_bytes;
+    unsigned long long *chunk_off;   // [nchunks + 1]
+    unsigned *wave_bytes;            // [nw rounded up to SCAN_CHUNK]
+    unsigned *wave_off;              // [nw rounded up to SCAN_CHUNK], offset inside the wave's chunk
+    unsigned *block_bytes;           // [nblocks]
 };
 
-__host__ __device__ inline size_t align8(size_t v) { return (v + 7) & ~(size_t)7; }
+__host__ __device__ inline size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
 
 __host__ __device__ inline Workspace carve(void *ws, long long nblocks)
 {
     const long long nw = (nblocks + 63) / 64;
+    const long long nchunks = (nw + SCAN_CHUNK - 1) / SCAN_CHUNK;
     unsigned char *p = reinterpret_cast<unsigned char *>(ws);
     Workspace w;
     w.total = reinterpret_cast<unsigned long long *>(p);
     w.error = reinterpret_cast<unsigned *>(p + 8);
-    w.wave_off = reinterpret_cast<unsigned long long *>(p + 16);
-    size_t off = 16 + (size_t)(nw + 1) * 8;
+    w.chunk_off = reinterpret_cast<unsigned long long *>(p + 16);
+    size_t off = align16(16 + (size_t)(nchunks + 1) * 8);
     w.wave_bytes = reinterpret_cast<unsigned *>(p + off);
-    off = align8(off + (size_t)nw * 4);
+    off += (size_t)nchunks * SCAN_CHUNK * 4;
+    w.wave_off = reinterpret_cast<unsigned *>(p + off);
+    off += (size_t)nchunks * SCAN_CHUNK * 4;
     w.block_bytes = reinterpret_cast<unsigned *>(p + off);
     return w;
 }
@@ -59,7 +69,8 @@ __host__ __device__ inline Workspace carve(void *ws, long long nblocks)
 size_t workspace_bytes(long long nblocks)
 {
     const long long nw = (nblocks + 63) / 64;
-    return align8(16 + (size_t)(nw + 1) * 8 + (size_t)nw * 4) + align8((size_t)nblocks * 4);
+    const long long nchunks = (nw + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    return align16(16 + (size_t)(nchunks + 1) * 8) + 2 * (size_t)nchunks * SCAN_CHUNK * 4 + align16((size_t)nblocks * 4);
 }
 
 // the wave's 64 x 128 B of coefficients -> swizzled LDS tile (LDS-DMA, as in k_inverse_fused)
@@ -91,25 +102,21 @@ __device__ __forceinline__ int coef(const unsigned (&w)[32], int p)
     return (p & 1) ? ((int)w[p >> 1] >> 16) : (int)(short)(w[p >> 1] & 0xFFFFu);
 }
 
-// bits of one block; sets bad when an amplitude needs more than 15 bits (util.py:140-149 BadRleCodeError)
-__device__ __forceinline__ unsigned block_bits(const unsigned (&w)[32], bool &bad)
+__device__ __forceinline__ int bit_length(unsigned v) { return 32 - __clz((int)v); }   // 0 for v == 0
+
+// Number of zero-chain codes of a block from its non-zero mask M (bit p = coefficient p != 0):
+// sum over the non-zeros of floor(run_before / 15) = #{run >= 15} + #{run >= 30} + #{>= 45} + #{>= 60}.
+// R_k has bit p set when positions p-k+1..p are all zero; a non-zero at p has run >= k iff bit p-1
+// of R_k is set (shifts bring in zeros at the bottom, so short prefixes never qualify).
+__device__ __forceinline__ unsigned chain_count(unsigned long long M)
 {
-    unsigned bits = 8;  // EOB
-    int prev = -1;
-#pragma unroll
-    for (int p = 0; p < 64; ++p) {
-        const int q = coef(w, p);
-        if (q != 0) {
-            const int run = p - prev - 1;
-            const int chains = (run >= 60) ? 4 : (run >= 45) ? 3 : (run >= 30) ? 2 : (run >= 15) ? 1 : 0;
-            const unsigned mag = (unsigned)(q < 0 ? -q : q);
-            const int bl = 32 - __clz((int)mag);
-            bad |= bl > 14;
-            bits += 8u * chains + 8u + (unsigned)bl + 1u;
-            prev = p;
-        }
-    }
-    return bits;
+    const unsigned long long z = ~M;
+    const unsigned long long r2 = z & (z << 1), r4 = r2 & (r2 << 2), r8 = r4 & (r4 << 4);
+    const unsigned long long r15 = r8 & (r8 << 7);
+    const unsigned long long r30 = r15 & (r15 << 15);
+    const unsigned long long r45 = r30 & (r15 << 30);
+    const unsigned long long r60 = r30 & (r30 << 30);
+    return __popcll((r15 << 1) & M) + __popcll((r30 << 1) & M) + __popcll((r45 << 1) & M) + __popcll((r60 << 1) & M);
 }
 
 __global__ __launch_bounds__(64) void k_rle_sizes(const int16_t *__restrict__ zz, int nblk, void *ws)
@@ -120,8 +127,21 @@ __global__ __launch_bounds__(64) void k_rle_sizes(const int16_t *__restrict__ zz
     stage_tile(zz, g0, nblk, lane, lds);
     unsigned w[32];
     load_block(lds, lane, w);
-    bool bad = false;
-    unsigned bytes = (block_bits(w, bad) + 7u) >> 3;
+    // branch-free: bits = EOB + sum over non-zeros (4 + 4 + 1 + bit_length) + 8 per zero chain
+    unsigned sum_bl = 0, max_bl = 0, mlo = 0, mhi = 0;
+#pragma unroll
+    for (int p = 0; p < 64; ++p) {
+        const int q = coef(w, p);
+        const unsigned bl = (unsigned)bit_length((unsigned)(q < 0 ? -q : q));
+        sum_bl += bl;
+        max_bl = max(max_bl, bl);
+        const unsigned bit = (q != 0) ? (1u << (p & 31)) : 0u;
+        if (p < 32) mlo |= bit; else mhi |= bit;
+    }
+    const unsigned long long M = ((unsigned long long)mhi << 32) | mlo;
+    const unsigned bits = 8u + sum_bl + 9u * (unsigned)__popcll(M) + 8u * chain_count(M);
+    bool bad = max_bl > 14;  // an amplitude beyond 15 bits (util.py:140-149 BadRleCodeError)
+    unsigned bytes = (bits + 7u) >> 3;
     if (g >= nblk) { bytes = 0; bad = false; }
     if (g < nblk) W.block_bytes[g] = bytes;
     if (__any(bad) && lane == 0) atomicOr(W.error, 1u);
@@ -131,39 +151,67 @@ __global__ __launch_bounds__(64) void k_rle_sizes(const int16_t *__restrict__ zz
     if (lane == 0) W.wave_bytes[blockIdx.x] = sum;
 }
 
-// exclusive scan of the per-wave totals by ONE workgroup of 1024 threads (chunked, carry in LDS)
-__global__ __launch_bounds__(1024) void k_scan_waves(int nwaves, void *ws, int nblk)
+// Two-level exclusive scan of the per-wave totals.  Level 1: one workgroup per SCAN_CHUNK waves,
+// 16 bytes per thread (coalesced), wave scan by __shfl_up + a 16-entry LDS carry.  Level 2: one
+// wave walks the chunk totals (<= 128 for 2^31 blocks).
+__global__ __launch_bounds__(1024) void k_scan_level1(int nwaves, void *ws, int nblk)
 {
-    __shared__ unsigned long long part[1024];
+    __shared__ unsigned carry[16];
     const Workspace W = carve(ws, nblk);
-    const int t = threadIdx.x;
-    const int per = (nwaves + 1023) / 1024;
-    const int lo = min(t * per, nwaves), hi = min(lo + per, nwaves);
-    unsigned long long s = 0;
-    for (int i = lo; i < hi; ++i) s += W.wave_bytes[i];
-    part[t] = s;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int i0 = blockIdx.x * SCAN_CHUNK + t * 4;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (i0 + 3 < nwaves) {
+        v = *reinterpret_cast<const u32x4 *>(W.wave_bytes + i0);
+    } else {
+        if (i0 + 0 < nwaves) v.x = W.wave_bytes[i0 + 0];
+        if (i0 + 1 < nwaves) v.y = W.wave_bytes[i0 + 1];
+        if (i0 + 2 < nwaves) v.z = W.wave_bytes[i0 + 2];
+    }
+    const unsigned s = v.x + v.y + v.z + v.w;
+    unsigned incl = s;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned u = __shfl_up(incl, d);
+        if (lane >= d) incl += u;
+    }
+    if (lane == 63) carry[wv] = incl;
     __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {                 // Hillis-Steele inclusive scan of the chunk sums
-        const unsigned long long v = (t >= d) ? part[t - d] : 0ull;
-        __syncthreads();
-        part[t] += v;
-        __syncthreads();
-    }
-    unsigned long long run = part[t] - s;                // exclusive prefix of this thread's chunk
-    for (int i = lo; i < hi; ++i) {
-        W.wave_off[i] = run;
-        run += W.wave_bytes[i];
-    }
-    if (t == 1023) {
-        W.wave_off[nwaves] = part[1023];
-        *W.total = part[1023];
-    }
+    unsigned base = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) base += (k < wv) ? carry[k] : 0u;
+    const unsigned e = base + incl - s;                   // exclusive prefix of this thread's 4 waves
+    *reinterpret_cast<u32x4 *>(W.wave_off + i0) = u32x4{e, e + v.x, e + v.x + v.y, e + v.x + v.y + v.z};
+    if (t == 1023) W.chunk_off[blockIdx.x] = (unsigned long long)(base + incl);   // chunk total, scanned next
 }
+
+__global__ __launch_bounds__(64) void k_scan_level2(int nchunks, void *ws, int nblk)
+{
+    const Workspace W = carve(ws, nblk);
+    if (threadIdx.x != 0) return;
+    unsigned long long run = 0;
+    for (int c = 0; c < nchunks; ++c) {
+        const unsigned long long t = W.chunk_off[c];
+        W.chunk_off[c] = run;
+        run += t;
+    }
+    W.chunk_off[nchunks] = run;
+    *W.total = run;
+}
+
+// Worst case per block: 63 non-zeros x (8 + 15) bits + DC 23 + EOB 8 < 1500 bits = 188 bytes.
+constexpr int EMIT_STAGE_BYTES = 64 * 192 + 32;
 
 __global__ __launch_bounds__(64) void k_rle_emit(const int16_t *__restrict__ zz, int nblk, const void *ws,
                                                  unsigned char *__restrict__ out)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[TILE_BYTES];
+    // [tile 8 KiB | bit staging]: the wave's bit string is assembled in LDS as big-endian 32-bit
+    // words (ds_or_b32 at each code's bit offset -- no per-byte loops), laid out at the same offset
+    // modulo 16 as the global destination, then byte-swapped and copied out with aligned 16-byte
+    // stores (single bytes only at the two ends, which neighbouring waves share).
+    // (the coefficient tile is dead once the block sits in registers, so the staging area reuses it)
+    __shared__ __attribute__((aligned(16))) unsigned char lds[EMIT_STAGE_BYTES];
+    unsigned *stage = reinterpret_cast<unsigned *>(lds);
     const Workspace W = carve(const_cast<void *>(ws), nblk);
     const int lane = threadIdx.x, g0 = blockIdx.x * 64, g = g0 + lane;
     stage_tile(zz, g0, nblk, lane, lds);
@@ -176,37 +224,57 @@ __global__ __launch_bounds__(64) void k_rle_emit(const int16_t *__restrict__ zz,
         const unsigned v = __shfl_up(incl, d);
         if (lane >= d) incl += v;
     }
-    if (g >= nblk) return;
-    unsigned char *p = out + W.wave_off[blockIdx.x] + (incl - mine);
+    const unsigned total = __shfl(incl, 63);
+    unsigned char *gdst = out + W.chunk_off[blockIdx.x / SCAN_CHUNK] + W.wave_off[blockIdx.x];   // wave-uniform
+    const unsigned skew = (unsigned)(reinterpret_cast<uintptr_t>(gdst) & 15u);
+    const unsigned end = skew + total;                    // bytes of staging in use
 
-    unsigned long long acc = 0;                           // MSB-first bit accumulator
-    int nb = 0;
-    auto put = [&](unsigned v, int n) {
-        acc = (acc << n) | v;
-        nb += n;
-        while (nb >= 8) {
-            *p++ = (unsigned char)(acc >> (nb - 8));
-            nb -= 8;
+    __syncthreads();                                      // every lane has its block in registers
+    for (unsigned c = lane * 16u; c < end + 16u; c += 64u * 16u)
+        *reinterpret_cast<u32x4 *>(reinterpret_cast<unsigned char *>(stage) + c) = u32x4{0u, 0u, 0u, 0u};
+    __syncthreads();
+
+    if (g < nblk) {
+        unsigned o = 8u * (skew + incl - mine);           // bit offset of the next code
+        auto put = [&](unsigned code, int n) {            // n <= 24 bits, MSB-first at bit offset o
+            const unsigned long long v = (unsigned long long)code << (64 - n - (int)(o & 31u));
+            atomicOr(&stage[o >> 5], (unsigned)(v >> 32));
+            const unsigned lo = (unsigned)v;
+            if (lo) atomicOr(&stage[(o >> 5) + 1], lo);
+            o += (unsigned)n;
+        };
+        int prev = -1;
+#pragma unroll
+        for (int p = 0; p < 64; ++p) {
+            const int q = coef(w, p);
+            if (q != 0) {
+                int run = p - prev - 1;
+                while (run >= 15) { put(0xF0u, 8); run -= 15; }           // (15, 0, 0): fifteen zeros
+                const unsigned mag = (unsigned)(q < 0 ? -q : q);
+                const int bl = bit_length(mag);
+                const unsigned hdr = ((unsigned)run << 4) | (unsigned)(bl + 1);   // 4-bit run, 4-bit size
+                put((hdr << (bl + 1)) | ((q > 0 ? 1u : 0u) << bl) | mag, 9 + bl);  // + sign + magnitude
+                prev = p;
+            }
         }
-    };
-    int prev = -1;
+        // EOB (8 zero bits) and the zero padding to the byte boundary are already there
+    }
+    __syncthreads();
+
+    unsigned char *gbase = gdst - skew;                   // 16-byte aligned
+    for (unsigned c = lane * 16u; c < end; c += 64u * 16u) {
+        u32x4 t = *reinterpret_cast<const u32x4 *>(reinterpret_cast<const unsigned char *>(stage) + c);
+        t.x = __builtin_bswap32(t.x); t.y = __builtin_bswap32(t.y);
+        t.z = __builtin_bswap32(t.z); t.w = __builtin_bswap32(t.w);
+        if (c >= skew && c + 16u <= end) {
+            __builtin_nontemporal_store(t, reinterpret_cast<u32x4 *>(gbase + c));
+        } else {
+            const unsigned wd[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
-    for (int i = 0; i < 64; ++i) {
-        const int q = coef(w, i);
-        if (q != 0) {
-            int run = i - prev - 1;
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (run >= 15) { put(0xF0u, 8); run -= 15; }          // (15, 0, 0): fifteen zeros
-            const unsigned mag = (unsigned)(q < 0 ? -q : q);
-            const int bl = 32 - __clz((int)mag);
-            put(((unsigned)run << 4) | (unsigned)(bl + 1), 8);         // 4-bit run, 4-bit size
-            put(((q > 0 ? 1u : 0u) << bl) | mag, bl + 1);              // sign + magnitude
-            prev = i;
+            for (unsigned k = 0; k < 16u; ++k)
+                if (c + k >= skew && c + k < end) gbase[c + k] = (unsigned char)(wd[k >> 2] >> (8u * (k & 3u)));
         }
     }
-    put(0u, 8);                                                       // EOB
-    if (nb) *p++ = (unsigned char)(acc << (8 - nb));                   // zero-pad to the byte boundary
 }
 
 int fail(int code, const char *msg)
@@ -247,8 +315,10 @@ int jpegx_entropy_sizes(const int16_t *d_zz, long long nblocks, void *d_workspac
     const int nblk = (int)nblocks, nw = (nblk + 63) / 64;
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(hipMemsetAsync(d_workspace, 0, 16, st));
+    const int nchunks = (nw + SCAN_CHUNK - 1) / SCAN_CHUNK;
     hipLaunchKernelGGL(k_rle_sizes, dim3(nw), dim3(64), 0, st, d_zz, nblk, d_workspace);
-    hipLaunchKernelGGL(k_scan_waves, dim3(1), dim3(1024), 0, st, nw, d_workspace, nblk);
+    hipLaunchKernelGGL(k_scan_level1, dim3(nchunks), dim3(1024), 0, st, nw, d_workspace, nblk);
+    hipLaunchKernelGGL(k_scan_level2, dim3(1), dim3(64), 0, st, nchunks, d_workspace, nblk);
     HIP_TRY(hipGetLastError());
     return JPEGX_OK;
 }

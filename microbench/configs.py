@@ -102,9 +102,35 @@ def inv(kind, out, planes=16):
             "frac_of_8TBps": round(blocks * bpb / ms / 1e6 / 8000, 4), "bytes_per_block": bpb}
 
 
+def entropy(kind, planes=16):
+    """Steps 7+8 on the device: sizes + scan, then emit; bytes = 2 reads of the stream + the output."""
+    import ctypes
+    L = jpegx.lib()
+    n = 4096
+    H = n * planes
+    src, zz = jpegx.DeviceBuffer(H * n * 4), jpegx.DeviceBuffer(H * n * 2)
+    for p in range(planes):
+        jpegx.generate_plane_device(src.ptr + p * n * n * 4, n, n, kind, seed=0, plane=p)
+    jpegx.forward_fused_device(src.ptr, H, n, zz.ptr, "qtable", 0.0, PIX)
+    nblocks = (H // 8) * (n // 8)
+    ws = jpegx.DeviceBuffer(L.jpegx_entropy_workspace_bytes(nblocks))
+    jpegx.check(L.jpegx_entropy_sizes(zz.ptr, nblocks, ws.ptr, None))
+    total = ctypes.c_ulonglong(0)
+    jpegx.check(L.jpegx_entropy_total(ws.ptr, ctypes.byref(total), None))
+    out = jpegx.DeviceBuffer(total.value)
+    ms_sizes = timed(lambda: jpegx.check(L.jpegx_entropy_sizes(zz.ptr, nblocks, ws.ptr, None)))
+    ms_emit = timed(lambda: jpegx.check(L.jpegx_entropy_emit(zz.ptr, nblocks, ws.ptr, out.ptr, None)))
+    nbytes = 2 * nblocks * 128 + total.value
+    ms = ms_sizes + ms_emit
+    return {"config": "entropy stage (run-length + bit packing) on %d planes 4096x4096" % planes, "kind": kind,
+            "ms_sizes_scan": round(ms_sizes, 4), "ms_emit": round(ms_emit, 4), "Mblocks_per_s": round(nblocks / ms / 1e3, 1),
+            "compressed_bytes_per_block": round(total.value / nblocks, 2), "GBps": round(nbytes / ms / 1e6, 1),
+            "frac_of_8TBps": round(nbytes / ms / 1e6 / 8000, 4)}
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", nargs="*", default=["c3", "c4", "inv"])
+    ap.add_argument("what", nargs="*", default=["c3", "c4", "inv", "entropy"])
     a = ap.parse_args()
     jpegx.require_device()
     for kind in ("smooth", "noise"):
@@ -115,6 +141,8 @@ def main():
         if "inv" in a.what:
             for out in ("f32", "i16", "u8"):
                 print(json.dumps(inv(kind, out)), flush=True)
+        if "entropy" in a.what:
+            print(json.dumps(entropy(kind)), flush=True)
 
 
 if __name__ == "__main__":
