@@ -232,6 +232,42 @@ def main():
                               "stream as raw bytes; not part of `value` (compute phase), see DESIGN.md multi-GPU"}
         except Exception as exc:   # the compute-phase result must survive a failing collective
             gather = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
+        # The same gather after the device entropy stage (steps 7+8, jpegx_entropy_*): the stream that
+        # crosses xGMI shrinks by the compression ratio.  Untimed extra; failures are reported, not fatal.
+        try:
+            import ctypes
+            nblk = blocks_per_step
+            t_ws = torch.empty(int(L.jpegx_entropy_workspace_bytes(nblk)), dtype=torch.uint8, device="cuda")
+            jpegx.check(L.jpegx_entropy_sizes(out_ptr, nblk, t_ws.data_ptr(), stream), "jpegx_entropy_sizes")
+            tot = ctypes.c_ulonglong(0)
+            jpegx.check(L.jpegx_entropy_total(t_ws.data_ptr(), ctypes.byref(tot), stream), "jpegx_entropy_total")
+            t_comp = torch.empty(max(1, tot.value), dtype=torch.uint8, device="cuda")
+            torch.cuda.synchronize()
+            te = time.perf_counter()
+            jpegx.check(L.jpegx_entropy_sizes(out_ptr, nblk, t_ws.data_ptr(), stream), "jpegx_entropy_sizes")
+            jpegx.check(L.jpegx_entropy_emit(out_ptr, nblk, t_ws.data_ptr(), t_comp.data_ptr(), stream), "jpegx_entropy_emit")
+            torch.cuda.synchronize()
+            te = time.perf_counter() - te
+            gather_stream(t_comp, dst=0)
+            torch.cuda.synchronize()
+            dist.barrier()
+            tc = time.perf_counter()
+            parts = gather_stream(t_comp, dst=0)
+            torch.cuda.synchronize()
+            dist.barrier()
+            tc = time.perf_counter() - tc
+            tct = torch.tensor([tc, float(tot.value)], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tct, op=dist.ReduceOp.MAX)
+            okc = True
+            if rank == 0:
+                okc = bool(torch.equal(parts[0], t_comp)) and len(parts) == world
+            gather["compressed"] = {"ms": round(float(tct[0].item()) * 1e3, 3), "bytes_per_rank_max": int(tct[1].item()),
+                                    "ratio_vs_int16_stream": round(out_bytes / max(1.0, float(tct[1].item())), 2),
+                                    "entropy_stage_ms_this_rank": round(te * 1e3, 3), "root_copy_ok": okc}
+        except Exception as exc:
+            if gather is None:
+                gather = {}
+            gather["compressed"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
 
     # HBM traffic per launch from the committed rocprofv3 PMC passes of this same command
     # (profiles/summarize.py; FETCH_SIZE doubled per the gfx950 correction).  Not collected live.
