@@ -1054,6 +1054,24 @@ void jpegx_internal_set_error(const char *msg) { snprintf(g_err, sizeof(g_err), 
 const char *jpegx_last_error(void) { return g_err; }
 int jpegx_version(void) { return JPEGX_VERSION; }
 
+int jpegx_init(int device)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n < 1) return fail(JPEGX_E_NODEVICE, "no usable HIP device");
+    if (device < 0 || device >= n) return fail(JPEGX_E_INVALID, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipFree(nullptr));   // forces context creation
+    return JPEGX_OK;
+}
+
+int jpegx_shutdown(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n < 1) return JPEGX_OK;
+    HIP_TRY(hipDeviceSynchronize());
+    return JPEGX_OK;
+}
+
 int jpegx_device_count(int *count)
 {
     if (!count) return fail(JPEGX_E_INVALID, "null count pointer");

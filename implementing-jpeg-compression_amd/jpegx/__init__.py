@@ -43,6 +43,8 @@ _u32 = _c.c_uint32
 
 # name -> argtypes; every symbol declared in include/jpegx.h (tests/test_abi.py checks the set)
 SIGNATURES = {
+    "jpegx_init": [_int],
+    "jpegx_shutdown": [],
     "jpegx_version": [],
     "jpegx_device_count": [_c.POINTER(_int)],
     "jpegx_set_device": [_int],
@@ -92,6 +94,7 @@ SIGNATURES = {
     "jpegx_entropy_total": [_vp, _c.POINTER(_c.c_ulonglong), _vp],
     "jpegx_entropy_emit": [_vp, _c.c_longlong, _vp, _vp, _vp],
     "jpegx_host_entropy_encode": [_vp, _c.c_longlong, _vp, _sz, _c.POINTER(_sz)],
+    "jpegx_host_entropy_decode": [_vp, _sz, _c.c_longlong, _vp],
 }
 RESTYPES = {"jpegx_entropy_workspace_bytes": _sz}   # everything else returns int
 
@@ -431,3 +434,12 @@ def compress_plane(plane, block_size=1, mode="qtable", param=0.0):
         for b in (din, dzz, dws, dout):
             if b is not None:
                 b.free()
+
+
+def entropy_decode(blob, nblocks):
+    """bytes -> int16 (nblocks, 64): RleBytestream.invert + RunLengthEncoding.invert (host, sequential)."""
+    buf = np.frombuffer(bytes(blob), dtype=np.uint8)
+    out = np.empty((int(nblocks), 64), dtype=np.int16)
+    check(lib().jpegx_host_entropy_decode(buf.ctypes.data if buf.size else None, buf.size, int(nblocks),
+                                          out.ctypes.data), "jpegx_host_entropy_decode")
+    return out

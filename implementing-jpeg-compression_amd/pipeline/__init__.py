@@ -187,8 +187,15 @@ def decompress_band(compression_result, config):
     fused = _accelerated(config)
     todo = list(reversed(step_classes))
     if fused and _stock_registry():
-        for cls in todo[:2]:                           # entropy stage (steps 8, 7) on the host
-            a = cls(config).invert(a)
+        if isinstance(a, (bytes, bytearray)):
+            # entropy stage inverted on the host by libjpegx's C++ parser (steps 8, 7)
+            import jpegx
+            rle = run_length_encoding.RunLengthEncoding(config)
+            hb, wb = rle._height_in_blocks(), rle._width_in_blocks()
+            a = jpegx.entropy_decode(a, hb * wb).reshape(hb, wb, 64)
+        else:
+            for cls in todo[:2]:
+                a = cls(config).invert(a)
         band = _back_end_fused(a, config)
         if band is not None:
             return band

@@ -74,6 +74,11 @@ typedef void *jpegx_stream_t; /* hipStream_t */
 typedef void *jpegx_event_t;  /* hipEvent_t  */
 
 /* ---- library / device management ------------------------------------------------------- */
+/* jpegx_init selects `device` for the calling thread and creates its HIP context up front (optional:
+ * every entry initialises lazily); jpegx_shutdown waits for outstanding work.  Neither resets the
+ * device, so the library can share a process with other HIP users (e.g. PyTorch).              */
+int jpegx_init(int device);
+int jpegx_shutdown(void);
 const char *jpegx_last_error(void);
 int jpegx_version(void);
 int jpegx_device_count(int *count);
@@ -174,6 +179,11 @@ int jpegx_entropy_emit(const int16_t *d_zz, long long nblocks, const void *d_wor
 /* host convenience; h_out may be NULL to query the size only */
 int jpegx_host_entropy_encode(const int16_t *h_zz, long long nblocks, uint8_t *h_out, size_t cap,
                               size_t *nbytes);
+
+/* Inverse of the entropy stage, ON THE HOST (sequential parse, as in the reference):
+ * RleBytestream.invert (pipeline/rle_byte_stream.py:61-88) + RunLengthEncoding.invert
+ * (pipeline/run_length_encoding.py:66-97) for dct_size 8: bytes -> int16 [nblocks][64].        */
+int jpegx_host_entropy_decode(const uint8_t *h_bytes, size_t nbytes, long long nblocks, int16_t *h_zz);
 
 /* ---- synchronous host-pointer conveniences (H2D, kernel, D2H on an internal stream) ------ */
 int jpegx_host_forward_fused(const float *h_in, int H, int W, ptrdiff_t pitch, int mode,

@@ -108,3 +108,38 @@ def test_jpeg_facade_round_trip_through_pil(gpu):
     assert out.size == (w, h) and out.mode == "YCbCr"
     err = np.abs(np.asarray(out, dtype=np.int64)[..., 0] - np.asarray(im, dtype=np.int64)[..., 0])
     assert err.mean() < 12
+
+
+def test_cli_compress_decompress_files(gpu, tmp_path):
+    """compress.py / decompress.py entry points on real files (reference: compress.py:6-20, decompress.py:5-10)."""
+    from PIL import Image
+    import compress
+    import decompress
+    import file_format
+    from jpegx import synth
+    h, w = 72, 104                                       # not multiples of 16: exercises both paddings
+    rgb = np.dstack([synth.generate_plane("smooth", h, w, seed=s, dtype=np.uint8) for s in (4, 5, 6)])
+    src, packed, back = tmp_path / "in.png", tmp_path / "out.bin", tmp_path / "back.png"
+    Image.fromarray(rgb, mode="RGB").save(src)
+    for bs, q in ((2, QuantizationMethod("qtable")), (1, QuantizationMethod("divide", divisor=10)), (4, None)):
+        compress.compress(str(src), str(packed), block_size=bs, dct_size=8, transform="DCT", quantization=q)
+        cfg, data = file_format.read_data(packed.read_bytes())
+        assert (cfg.width, cfg.height, cfg.block_size, cfg.dct_size) == (w, h, bs, 8)
+        decompress.decompress(str(packed), str(back))
+        out = np.asarray(Image.open(back).convert("RGB"), dtype=np.int64)
+        assert out.shape == rgb.shape
+        assert np.abs(out - rgb.astype(np.int64)).mean() < (6 if bs == 1 else 16)
+
+
+def test_decompress_band_fast_path_equals_generic_path(gpu, golden):
+    """The fused back end (C++ entropy parse + one launch) and the step-by-step walk agree."""
+    from pipeline.base import step_classes
+    c = golden("pooled128")
+    band = c["input"].astype(np.int64)
+    cfg = config_for(c, QuantizationMethod("qtable"))
+    blob = compress_band(band, cfg)
+    fast = decompress_band(blob, cfg)
+    a = blob
+    for cls in reversed(step_classes):                   # the reference's plain loop
+        a = cls(cfg).invert(a)
+    assert np.array_equal(fast, a) and np.array_equal(fast, c["band_qtable"])

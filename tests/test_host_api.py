@@ -258,3 +258,20 @@ def test_cli_flag_surface():
     assert compress.quantization_from_args(args).quantizer.divisor == 12
     args = compress.build_parser().parse_args(["a", "b", "--quantization", "none"])
     assert compress.quantization_from_args(args) is None
+
+
+# ---- libjpegx host-side entropy decoder (C++, no GPU needed) ----------------------------------
+def test_host_entropy_decoder_inverts_the_python_encoder(golden):
+    import jpegx
+    c = golden("noise64")
+    for suffix in ("qtable", "none", "divide40", "discard2"):
+        zz = c["zz_" + suffix]
+        blob = RleBytestream(None).execute(RunLengthEncoding(None).execute(zz.astype(float)))
+        back = jpegx.entropy_decode(blob, zz.shape[0] * zz.shape[1]).reshape(zz.shape)
+        assert np.array_equal(back, zz)
+        cfg = Configuration(width=64, height=64, block_size=1)
+        ref = RunLengthEncoding(cfg).invert(RleBytestream(cfg).invert(blob))
+        assert np.array_equal(ref, zz)
+    for bad in (b"", b"\x12", b"\xf0\xf0\xf0\xf0\xf0\x00"):
+        with pytest.raises(jpegx.JpegxError):
+            jpegx.entropy_decode(bad, 1)
