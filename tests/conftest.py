@@ -24,6 +24,21 @@ CASES = ["noise64", "smooth64", "ties128", "pooled128", "ragged20x28", "extremes
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    _ensure_built()
+
+
+def _ensure_built():
+    """Bring libjpegx.so and the oracle up to date (no-ops when current).  On a box without hipcc
+    (never the case for the two images this runs on) the prebuilt files that travelled are used."""
+    import shutil
+    import subprocess
+    if shutil.which("make") is None:
+        return
+    hipcc = shutil.which("hipcc") or ("/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else None)
+    if hipcc is not None:
+        subprocess.check_call(["make", "-s", "-C", os.path.join(PKG, "csrc"), "HIPCC=" + hipcc])
+    if shutil.which("gcc") is not None:
+        subprocess.check_call(["make", "-s", "-C", os.path.join(REPO, "oracle")])
 
 
 @pytest.fixture(scope="session")
