@@ -144,6 +144,63 @@ __device__ __forceinline__ double coop_inv_exact(double z_own, double *sA, doubl
 }
 
 // ------------------------------------------------------------------------------------------------
+// pieces shared by the forward kernels
+// ------------------------------------------------------------------------------------------------
+
+// Quantise the 64 coefficients of v (natural order) in zigzag order and pack them as int16 pairs
+// (pipeline/quantization.py:8-18 + pipeline/zigzag_order.py:85-99; the zigzag is a compile-time
+// renaming).  Returns the worst rounding margin max(|t - rint(t)| + E / q): the block is safe iff
+// it stays below 1/2.  PIXEL: values provably fit int16, no saturation needed.
+template <bool PIXEL, bool DC_EXACT>
+__device__ __forceinline__ float quantise_zigzag_pack(const float (&v)[64], const QuantParams &prm, float E,
+                                                      unsigned (&pk)[32])
+{
+    float worst = 0.f;
+#pragma unroll
+    for (int p = 0; p < 64; p += 2) {
+        int q[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int n = kZZ.v[p + h];
+            const float rq = prm.rq32[n];
+            const float t = v[n] * rq;
+            const float r = rintf(t);
+            if (!(DC_EXACT && n == 0)) worst = fmaxf(worst, fmaf(E, rq, fabsf(t - r)));
+            q[h] = (int)r;
+        }
+        if (PIXEL) {
+            pk[p >> 1] = ((unsigned)q[0] & 0xFFFFu) | ((unsigned)q[1] << 16);
+        } else {
+            const int a = min(max(q[0], -32768), 32767), b = min(max(q[1], -32768), 32767);
+            pk[p >> 1] = ((unsigned)a & 0xFFFFu) | ((unsigned)b << 16);
+        }
+    }
+    return worst;
+}
+
+// The wave's 64 x 128 B output tile -> 8 coalesced 1 KiB stores into the zigzag stream.
+template <bool NT>
+__device__ __forceinline__ void store_tile(const unsigned char *tile, int16_t *out, int g0, int nblk, int lane)
+{
+    unsigned char *dst = reinterpret_cast<unsigned char *>(out) + (size_t)g0 * 128;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int row = i * 8 + (lane >> 3), c = lane & 7;
+        const u32x4 q = *reinterpret_cast<const u32x4 *>(tile + tile_off(row, c));
+        if (g0 + row < nblk) st_u32x4<NT>(dst + (size_t)row * 128 + c * 16, q);
+    }
+}
+
+// exact-tier census (jpegx_set_debug_counters): [0] += flagged blocks, [1] += blocks of this wave
+__device__ __forceinline__ void census(unsigned long long *counters, unsigned long long flagged, int remaining, int lane)
+{
+    if (counters != nullptr && lane == 0) {
+        atomicAdd(&counters[0], (unsigned long long)__popcll(flagged));
+        atomicAdd(&counters[1], (unsigned long long)min(64, remaining));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // fused forward: DCT + quantise + zigzag.  VAR bit0 = PIXEL_INPUT, bit1 = DC exact.
 // BS = mean-pool factor of the fused SubSampling prologue (1 = none).
 // ------------------------------------------------------------------------------------------------
@@ -281,27 +338,8 @@ __global__ __launch_bounds__(64) void k_forward_fused(const float *__restrict__ 
     const float E = jpegx_fwd_err_bound(S) * ((PIXEL || BS == 1) ? 1.0f : 1.0f + (BS * BS) / 16.0f);
 
     // quantise in zigzag order, pack pairs, track the worst rounding margin
-    float worst = 0.f;
     unsigned pk[32];
-#pragma unroll
-    for (int p = 0; p < 64; p += 2) {
-        int q[2];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int n = kZZ.v[p + h];
-            const float rq = prm.rq32[n];
-            const float t = v[n] * rq;
-            const float r = rintf(t);
-            if (!(DC_EXACT && n == 0)) worst = fmaxf(worst, fmaf(E, rq, fabsf(t - r)));
-            q[h] = (int)r;
-        }
-        if (PIXEL) {
-            pk[p >> 1] = ((unsigned)q[0] & 0xFFFFu) | ((unsigned)q[1] << 16);
-        } else {
-            const int a = min(max(q[0], -32768), 32767), b = min(max(q[1], -32768), 32767);
-            pk[p >> 1] = ((unsigned)a & 0xFFFFu) | ((unsigned)b << 16);
-        }
-    }
+    const float worst = quantise_zigzag_pack<PIXEL, DC_EXACT>(v, prm, E, pk);
 
     // park the lane's 128 B in the swizzled tile
 #pragma unroll
@@ -311,10 +349,7 @@ __global__ __launch_bounds__(64) void k_forward_fused(const float *__restrict__ 
 
     // exact tier for blocks that sit within the error bound of a rounding boundary
     unsigned long long flagged = __ballot(valid && !(worst < 0.5f));
-    if (counters != nullptr && lane == 0) {
-        atomicAdd(&counters[0], (unsigned long long)__popcll(flagged));
-        atomicAdd(&counters[1], (unsigned long long)min(64, nblk - g0));
-    }
+    census(counters, flagged, nblk - g0, lane);
     if (prm.tune & 1) flagged = 0;
     __syncthreads();
     while (flagged) {
@@ -343,13 +378,7 @@ __global__ __launch_bounds__(64) void k_forward_fused(const float *__restrict__ 
     __syncthreads();
 
     // coalesced write-back: 8 x 1 KiB per wave
-    unsigned char *dst = reinterpret_cast<unsigned char *>(out) + (size_t)g0 * 128;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int row = i * 8 + (lane >> 3), c = lane & 7;
-        const u32x4 q = *reinterpret_cast<const u32x4 *>(lds + tile_off(row, c));
-        if (g0 + row < nblk) st_u32x4<NT>(dst + (size_t)row * 128 + c * 16, q);
-    }
+    store_tile<NT>(lds, out, g0, nblk, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -429,33 +458,11 @@ __global__ __launch_bounds__(64) void k_forward_fused_strip(const float *__restr
     if (PIXEL) S = v[0];
     const float E = jpegx_fwd_err_bound(S);
 
-    float worst = 0.f;
     unsigned pk[32];
-#pragma unroll
-    for (int p = 0; p < 64; p += 2) {
-        int q[2];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int n = kZZ.v[p + h];
-            const float rq = prm.rq32[n];
-            const float t = v[n] * rq;
-            const float r = rintf(t);
-            if (!(DC_EXACT && n == 0)) worst = fmaxf(worst, fmaf(E, rq, fabsf(t - r)));
-            q[h] = (int)r;
-        }
-        if (PIXEL) {
-            pk[p >> 1] = ((unsigned)q[0] & 0xFFFFu) | ((unsigned)q[1] << 16);
-        } else {
-            const int a = min(max(q[0], -32768), 32767), b = min(max(q[1], -32768), 32767);
-            pk[p >> 1] = ((unsigned)a & 0xFFFFu) | ((unsigned)b << 16);
-        }
-    }
+    const float worst = quantise_zigzag_pack<PIXEL, DC_EXACT>(v, prm, E, pk);
 
     unsigned long long flagged = __ballot(valid && !(worst < 0.5f));
-    if (counters != nullptr && lane == 0) {
-        atomicAdd(&counters[0], (unsigned long long)__popcll(flagged));
-        atomicAdd(&counters[1], (unsigned long long)min(64, nblk - g0));
-    }
+    census(counters, flagged, nblk - g0, lane);
     if (prm.tune & 1) flagged = 0;
     while (flagged) {   // exact tier, inputs re-read from the strip still resident in LDS
         const int b = __ffsll((long long)flagged) - 1;
@@ -483,13 +490,7 @@ __global__ __launch_bounds__(64) void k_forward_fused_strip(const float *__restr
     for (int c = 0; c < 8; ++c)
         *reinterpret_cast<u32x4 *>(lds + tile_off(lane, c)) = u32x4{pk[c * 4 + 0], pk[c * 4 + 1], pk[c * 4 + 2], pk[c * 4 + 3]};
     __syncthreads();
-    unsigned char *dst = reinterpret_cast<unsigned char *>(out) + (size_t)g0 * 128;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int row = i * 8 + (lane >> 3), c = lane & 7;
-        const u32x4 q = *reinterpret_cast<const u32x4 *>(lds + tile_off(row, c));
-        if (g0 + row < nblk) st_u32x4<NT>(dst + (size_t)row * 128 + c * 16, q);
-    }
+    store_tile<NT>(lds, out, g0, nblk, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -667,10 +668,7 @@ __global__ __launch_bounds__(64) void k_inverse_fused(const int16_t *__restrict_
         v[n] = r;
     }
     unsigned long long flagged = __ballot(valid && !(worst + E < 0.5f));
-    if (counters != nullptr && lane == 0) {
-        atomicAdd(&counters[0], (unsigned long long)__popcll(flagged));
-        atomicAdd(&counters[1], (unsigned long long)min(64, nblk - g0));
-    }
+    census(counters, flagged, nblk - g0, lane);
     if (prm.tune & 1) flagged = 0;
     while (flagged) {
         const int b = __ffsll((long long)flagged) - 1;
