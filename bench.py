@@ -58,24 +58,27 @@ def parse_args():
     return ap.parse_args()
 
 
-def cpu_baseline(size, kind):
-    """Reference-shaped CPU pipeline on this host, single core (the reference is single-threaded)."""
+def cpu_baseline(size, kind, sample_planes=3):
+    """Reference-shaped CPU pipeline on this host, single core (the reference is single-threaded).
+
+    Sample: `sample_planes` distinct size x size planes through the faithful per-block Python/NumPy loop
+    (about 10-15 s on a current server core), then the scalar C oracle on the same planes."""
     import oracle
     from oracle import ref_loop
     from jpegx import synth
-    plane = synth.generate_plane(kind, size, size, seed=0, plane=0)
-    nblk = (size // 8) ** 2
-    ref_loop.forward_qtable(plane[:64, :64].astype(np.float64))          # warm-up
+    planes = [synth.generate_plane(kind, size, size, seed=0, plane=p) for p in range(sample_planes)]
+    nblk = (size // 8) ** 2 * sample_planes
+    ref_loop.forward_qtable(planes[0][:64, :64].astype(np.float64))          # warm-up
     t0 = time.perf_counter()
-    zz_py = ref_loop.forward_qtable(plane.astype(np.float64))
+    zz_py = [ref_loop.forward_qtable(p.astype(np.float64)) for p in planes]
     t_py = time.perf_counter() - t0
     best_c = None
     for _ in range(3):
         t0 = time.perf_counter()
-        zz_c = oracle.forward_f32(plane, "qtable")
+        zz_c = [oracle.forward_f32(p, "qtable") for p in planes]
         dt = time.perf_counter() - t0
         best_c = dt if best_c is None else min(best_c, dt)
-    agree = int(np.count_nonzero(zz_py.astype(np.int16) != zz_c))
+    agree = int(sum(np.count_nonzero(a.astype(np.int16) != b) for a, b in zip(zz_py, zz_c)))
     cores_avail = os.cpu_count()
     try:
         with open("/proc/cpuinfo") as f:
@@ -84,8 +87,8 @@ def cpu_baseline(size, kind):
         model = "unknown"
     return {
         "value": round(nblk / t_py / 1e6, 6), "unit": "Mblocks/s", "cores": 1, "kind": "port",
-        "sample": "one %dx%d %s plane (%d blocks), oracle/ref_loop.py per-block Python/NumPy loop "
-                  "(reference call structure), %.1f s" % (size, size, kind, nblk, t_py),
+        "sample": "%d %dx%d %s planes (%d blocks), oracle/ref_loop.py per-block Python/NumPy loop "
+                  "(reference call structure), %.1f s" % (sample_planes, size, size, kind, nblk, t_py),
         "c_oracle_mblocks_per_s": round(nblk / best_c / 1e6, 4),
         "c_oracle_note": "oracle/jpegx_oracle.c, scalar C in the reference's fp64 order, 1 core, best of 3",
         "python_vs_c_mismatches": agree, "host_cpu": model, "host_cores_available": cores_avail,

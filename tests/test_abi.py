@@ -67,6 +67,25 @@ def test_argument_validation_happens_before_any_device_work():
     assert b"multiples of 8" in L.jpegx_last_error()
 
 
+def test_size_limits_and_empty_planes_are_rejected():
+    """Zero-sized planes (the reference raises EmptyArrayError, util.py:30-31) and launches beyond
+    2^31 blocks are refused by validation, before any device work."""
+    import jpegx
+    L = jpegx.lib()
+    buf = ctypes.create_string_buffer(64)
+    p = ctypes.addressof(buf) & ~15
+    assert L.jpegx_forward_fused(p, 0, 8, 8, 3, 0.0, 0, p, None) == -1
+    assert L.jpegx_forward_fused(p, 8, 0, 8, 3, 0.0, 0, p, None) == -1
+    big = 8 * (1 << 16)
+    assert L.jpegx_forward_fused(p, big, big, big, 3, 0.0, 0, p, None) == -1
+    assert b"2^31" in L.jpegx_last_error()
+    assert L.jpegx_inverse_fused(p, big, big, 3, 0.0, 0, p, big, 0, None) == -1
+    assert L.jpegx_entropy_sizes(p, 0, p, None) == -1
+    assert L.jpegx_forward_fused(p, 8, 8, 8, 7, 0.0, 0, p, None) == -1          # unknown quantiser
+    assert L.jpegx_forward_fused(p, 8, 8, 8, 1, -2.0, 0, p, None) == -1         # discard: negative keep
+    assert L.jpegx_forward_fused_pooled(p, 8, 8, 24, 3, 3, 0.0, 0, p, None) == -4   # block_size 3: unsupported
+
+
 def test_product_never_imports_the_oracle():
     """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may touch oracle/."""
     pkg = os.path.join(REPO, "implementing-jpeg-compression_amd")

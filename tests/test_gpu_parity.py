@@ -243,3 +243,61 @@ def test_inverse_u8_with_fused_inflate(gpu, bs):
         want = np.repeat(np.repeat(want, bs, axis=0), bs, axis=1)
         got = gpu.inverse_fused_u8(zz, "qtable", inflate=bs)
         assert got.shape == want.shape and np.array_equal(got, want)
+
+
+def test_config3_full_size_ycbcr420(gpu):
+    """BASELINE config 3 at full size: 8192x8192 Y + two 2x2-pooled chroma planes, bit-exact vs the oracle."""
+    n = 8192
+    y = gpu.synth.generate_plane("smooth", n, n, seed=0, plane=0)
+    assert np.array_equal(gpu.forward_fused(y, "qtable"), oracle.forward_f32(y, "qtable"))
+    del y
+    for plane in (1, 2):
+        c = gpu.synth.generate_plane("smooth", n, n, seed=0, plane=plane)
+        pooled = c.reshape(n // 2, 2, n // 2, 2).sum(axis=(1, 3), dtype=np.float32) * np.float32(0.25)
+        assert np.array_equal(gpu.forward_fused_pooled(c, 2, "qtable"), oracle.forward_f32(pooled, "qtable"))
+
+
+def test_batched_launch_equals_per_plane_launches(gpu):
+    """Size-independent property used at config-5 scale: a stack of planes processed as ONE tall plane
+    gives exactly the concatenation of the per-plane streams (blocks never interact)."""
+    import hashlib
+    n, planes = 1024, 6
+    stack = np.concatenate([gpu.synth.generate_plane("noise", n, n, seed=2, plane=p) for p in range(planes)], axis=0)
+    whole = gpu.forward_fused(stack, "qtable")
+    digests = []
+    for p in range(planes):
+        one = gpu.forward_fused(stack[p * n:(p + 1) * n], "qtable")
+        assert np.array_equal(one, whole[p * (n // 8):(p + 1) * (n // 8)])
+        digests.append(hashlib.sha256(one.tobytes()).digest())
+    assert hashlib.sha256(b"".join(digests)).hexdigest() == hashlib.sha256(
+        b"".join(hashlib.sha256(whole[p * (n // 8):(p + 1) * (n // 8)].tobytes()).digest() for p in range(planes))).hexdigest()
+    # and the round trip of the stack equals the oracle's for one plane
+    rec = gpu.inverse_fused(whole, "qtable", out="u8")
+    want = np.clip(oracle.inverse_i16(oracle.forward_f32(stack[:n], "qtable"), "qtable"), 0, 255)
+    assert np.array_equal(rec[:n], want)
+
+
+def test_random_shapes_modes_and_values_against_oracle(gpu):
+    """Seeded fuzz: random plane shapes, quantisers, parameters and value ranges (incl. negative and
+    fractional fp32 samples, which take the generic non-pixel variant)."""
+    rng = np.random.default_rng(20261004)
+    for trial in range(40):
+        h, w = 8 * int(rng.integers(1, 20)), 8 * int(rng.integers(1, 90))
+        kind = trial % 4
+        if kind == 0:
+            a = rng.integers(0, 256, (h, w)).astype(np.float32)
+        elif kind == 1:
+            a = (rng.integers(0, 1024, (h, w)) / 4.0).astype(np.float32)          # quarter steps
+        elif kind == 2:
+            a = rng.normal(0, 300, (h, w)).astype(np.float32)                     # signed, fractional
+        else:
+            a = (rng.integers(-2000, 2000, (h, w)) * 0.5).astype(np.float32)
+        mode, param = [("qtable", 0.0), ("none", 0.0), ("divide", float(rng.integers(1, 200))),
+                       ("discard", float(rng.integers(0, 10)))][int(rng.integers(0, 4))]
+        want = oracle.forward_f32(a, mode, param)
+        got = gpu.forward_fused(a, mode, param)
+        assert np.array_equal(got, want), (trial, h, w, mode, param)
+        if np.abs(want).max() < 16384:
+            assert gpu.entropy_encode(want) == oracle.rle_bytestream(want)
+        back = gpu.inverse_fused(want, mode, param, out="f32")
+        assert np.array_equal(back.astype(np.int64), oracle.inverse_i16(want, mode, param)), (trial, mode, param)
