@@ -68,3 +68,148 @@ extern "C" int jpegx_host_entropy_decode(const uint8_t *h_bytes, size_t nbytes, 
     }
     return JPEGX_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Multi-GPU gather of the coefficient / entropy-coded stream over RCCL: the one
+// exchange step of the path.  librccl is bound at run time (dlopen) so that libjpegx.so itself
+// carries no RCCL dependency; an RCCL that is already loaded in the process (e.g. PyTorch's) is
+// reused.  ncclGather-style: grouped ncclSend (every rank) / ncclRecv (root, one per rank) of raw
+// bytes, enqueued on the caller's stream.  The unique id is exchanged by the caller (any side
+// channel: torch.distributed, MPI, a file).
+// ------------------------------------------------------------------------------------------------
+#include <dlfcn.h>
+#include <string.h>
+
+namespace {
+
+typedef struct { char internal[128]; } rccl_unique_id;
+typedef int (*fn_get_unique_id)(rccl_unique_id *);
+typedef int (*fn_comm_init_rank)(void **, int, rccl_unique_id, int);
+typedef int (*fn_comm_destroy)(void *);
+typedef int (*fn_send)(const void *, size_t, int, int, void *, void *);
+typedef int (*fn_recv)(void *, size_t, int, int, void *, void *);
+typedef int (*fn_group)(void);
+typedef const char *(*fn_error_string)(int);
+
+struct Rccl {
+    void *handle = nullptr;
+    fn_get_unique_id get_unique_id = nullptr;
+    fn_comm_init_rank comm_init_rank = nullptr;
+    fn_comm_destroy comm_destroy = nullptr;
+    fn_send send = nullptr;
+    fn_recv recv = nullptr;
+    fn_group group_start = nullptr, group_end = nullptr;
+    fn_error_string error_string = nullptr;
+};
+
+Rccl g_rccl;
+
+int load_rccl()
+{
+    if (g_rccl.handle) return JPEGX_OK;
+    static const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void *h = nullptr;
+    for (const char *n : names)                      // prefer a copy that is already in the process
+        if ((h = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL))) break;
+    if (!h)
+        for (const char *n : names)
+            if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!h) {
+        jpegx_internal_set_error("librccl.so could not be loaded (multi-GPU gather unavailable)");
+        return JPEGX_E_UNSUPPORTED;
+    }
+    Rccl r;
+    r.handle = h;
+    r.get_unique_id = (fn_get_unique_id)dlsym(h, "ncclGetUniqueId");
+    r.comm_init_rank = (fn_comm_init_rank)dlsym(h, "ncclCommInitRank");
+    r.comm_destroy = (fn_comm_destroy)dlsym(h, "ncclCommDestroy");
+    r.send = (fn_send)dlsym(h, "ncclSend");
+    r.recv = (fn_recv)dlsym(h, "ncclRecv");
+    r.group_start = (fn_group)dlsym(h, "ncclGroupStart");
+    r.group_end = (fn_group)dlsym(h, "ncclGroupEnd");
+    r.error_string = (fn_error_string)dlsym(h, "ncclGetErrorString");
+    if (!r.get_unique_id || !r.comm_init_rank || !r.comm_destroy || !r.send || !r.recv || !r.group_start || !r.group_end) {
+        jpegx_internal_set_error("librccl.so lacks a required symbol");
+        return JPEGX_E_UNSUPPORTED;
+    }
+    g_rccl = r;
+    return JPEGX_OK;
+}
+
+int rccl_fail(const char *what, int code)
+{
+    char buf[300];
+    snprintf(buf, sizeof(buf), "%s failed: %s", what, g_rccl.error_string ? g_rccl.error_string(code) : "RCCL error");
+    jpegx_internal_set_error(buf);
+    return JPEGX_E_HIP;
+}
+
+struct Comm {
+    void *nccl;
+    int nranks, rank;
+};
+
+const int kNcclUint8 = 1;
+
+}  // namespace
+
+extern "C" {
+
+int jpegx_comm_unique_id(void *id128)
+{
+    if (!id128) return fail("null id buffer");
+    int rc = load_rccl();
+    if (rc) return rc;
+    rccl_unique_id id;
+    int e = g_rccl.get_unique_id(&id);
+    if (e) return rccl_fail("ncclGetUniqueId", e);
+    memcpy(id128, id.internal, 128);
+    return JPEGX_OK;
+}
+
+int jpegx_comm_create(jpegx_comm_t *comm, int nranks, int rank, const void *id128)
+{
+    if (!comm || !id128) return fail("null pointer");
+    if (nranks < 1 || rank < 0 || rank >= nranks) return fail("bad rank / nranks");
+    int rc = load_rccl();
+    if (rc) return rc;
+    rccl_unique_id id;
+    memcpy(id.internal, id128, 128);
+    void *c = nullptr;
+    int e = g_rccl.comm_init_rank(&c, nranks, id, rank);   // binds to the calling thread's current HIP device
+    if (e) return rccl_fail("ncclCommInitRank", e);
+    *comm = new Comm{c, nranks, rank};
+    return JPEGX_OK;
+}
+
+int jpegx_comm_destroy(jpegx_comm_t comm)
+{
+    if (!comm) return JPEGX_OK;
+    Comm *c = static_cast<Comm *>(comm);
+    int e = g_rccl.comm_destroy(c->nccl);
+    delete c;
+    return e ? rccl_fail("ncclCommDestroy", e) : JPEGX_OK;
+}
+
+int jpegx_comm_gather_bytes(jpegx_comm_t comm, const void *d_send, size_t send_bytes, void *d_recv,
+                            const size_t *recv_bytes, const size_t *recv_offsets, int root, jpegx_stream_t stream)
+{
+    if (!comm) return fail("null communicator");
+    Comm *c = static_cast<Comm *>(comm);
+    if (root < 0 || root >= c->nranks) return fail("bad root rank");
+    if (c->rank == root && (!d_recv || !recv_bytes || !recv_offsets)) return fail("root needs receive buffer, sizes and offsets");
+    if (send_bytes && !d_send) return fail("null send buffer");
+    int e = g_rccl.group_start();
+    if (e) return rccl_fail("ncclGroupStart", e);
+    if (c->rank == root)
+        for (int r = 0; r < c->nranks && !e; ++r)
+            if (recv_bytes[r])
+                e = g_rccl.recv(static_cast<char *>(d_recv) + recv_offsets[r], recv_bytes[r], kNcclUint8, r, c->nccl, stream);
+    if (!e && send_bytes) e = g_rccl.send(d_send, send_bytes, kNcclUint8, root, c->nccl, stream);
+    int e2 = g_rccl.group_end();
+    if (e) return rccl_fail("ncclSend/ncclRecv", e);
+    if (e2) return rccl_fail("ncclGroupEnd", e2);
+    return JPEGX_OK;
+}
+
+}  // extern "C"

@@ -95,6 +95,10 @@ SIGNATURES = {
     "jpegx_entropy_emit": [_vp, _c.c_longlong, _vp, _vp, _vp],
     "jpegx_host_entropy_encode": [_vp, _c.c_longlong, _vp, _sz, _c.POINTER(_sz)],
     "jpegx_host_entropy_decode": [_vp, _sz, _c.c_longlong, _vp],
+    "jpegx_comm_unique_id": [_vp],
+    "jpegx_comm_create": [_c.POINTER(_vp), _int, _int, _vp],
+    "jpegx_comm_destroy": [_vp],
+    "jpegx_comm_gather_bytes": [_vp, _vp, _sz, _vp, _c.POINTER(_sz), _c.POINTER(_sz), _int, _vp],
 }
 RESTYPES = {"jpegx_entropy_workspace_bytes": _sz}   # everything else returns int
 

@@ -58,3 +58,54 @@ def gather_stream(local, dst=0, group=None):
     if rank != dst:
         return None
     return [b[:n].view(dtype) for b, n in zip(bufs, sizes)]
+
+
+class NativeComm:
+    """RCCL communicator owned by libjpegx (jpegx_comm_*): the PyTorch-free form of the gather.
+
+    ``exchange_id`` is any callable that takes rank 0's 128-byte id (bytes on rank 0, None elsewhere)
+    and returns the id on every rank -- e.g. an MPI bcast, a shared file, or
+    ``NativeComm.exchange_via_torch`` when a torch.distributed group (gloo is enough) exists.
+    """
+
+    def __init__(self, nranks, rank, exchange_id):
+        import ctypes
+        import jpegx
+        self._jpegx = jpegx
+        L = jpegx.lib()
+        ident = None
+        if rank == 0:
+            buf = ctypes.create_string_buffer(128)
+            jpegx.check(L.jpegx_comm_unique_id(buf), "jpegx_comm_unique_id")
+            ident = buf.raw
+        ident = exchange_id(ident)
+        handle = ctypes.c_void_p()
+        jpegx.check(L.jpegx_comm_create(ctypes.byref(handle), nranks, rank, ident), "jpegx_comm_create")
+        self.handle, self.nranks, self.rank = handle.value, nranks, rank
+
+    @staticmethod
+    def exchange_via_torch(ident):
+        import torch.distributed as dist
+        box = [ident]
+        dist.broadcast_object_list(box, src=0)
+        return box[0]
+
+    def gather_bytes(self, send_ptr, send_bytes, recv_ptr=None, recv_bytes=None, root=0, stream=None):
+        """Every rank sends ``send_bytes`` from ``send_ptr``; the root lays rank r's bytes out at the
+        running offset of ``recv_bytes`` inside ``recv_ptr``.  Enqueues on ``stream``."""
+        import ctypes
+        n = self.nranks
+        sizes = (ctypes.c_size_t * n)(*([0] * n))
+        offs = (ctypes.c_size_t * n)(*([0] * n))
+        if self.rank == root:
+            run = 0
+            for r in range(n):
+                sizes[r], offs[r] = int(recv_bytes[r]), run
+                run += int(recv_bytes[r])
+        self._jpegx.check(self._jpegx.lib().jpegx_comm_gather_bytes(self.handle, send_ptr, int(send_bytes), recv_ptr, sizes, offs,
+                                                                      root, stream), "jpegx_comm_gather_bytes")
+
+    def close(self):
+        if self.handle:
+            self._jpegx.lib().jpegx_comm_destroy(self.handle)
+            self.handle = None

@@ -185,6 +185,22 @@ int jpegx_host_entropy_encode(const int16_t *h_zz, long long nblocks, uint8_t *h
  * (pipeline/run_length_encoding.py:66-97) for dct_size 8: bytes -> int16 [nblocks][64].        */
 int jpegx_host_entropy_decode(const uint8_t *h_bytes, size_t nbytes, long long nblocks, int16_t *h_zz);
 
+/* ---- multi-GPU: the one exchange step of the path ---------------------------
+ * ncclGather-style gather of raw bytes (the int16 zigzag stream or the entropy-coded stream) over
+ * RCCL/xGMI.  No reference counterpart (the reference is single-process).  librccl is bound at run
+ * time; JPEGX_E_UNSUPPORTED if it cannot be loaded.  One communicator per process/GPU:
+ *   rank 0: jpegx_comm_unique_id -> ship the 128 bytes to every rank (any side channel) ->
+ *   all ranks: jpegx_comm_create(nranks, rank, id) on the thread's current device ->
+ *   jpegx_comm_gather_bytes(...): every rank sends send_bytes; the root receives recv_bytes[r] bytes
+ *   from rank r at d_recv + recv_offsets[r].  Enqueued on `stream`.                              */
+typedef void *jpegx_comm_t;
+int jpegx_comm_unique_id(void *id128);
+int jpegx_comm_create(jpegx_comm_t *comm, int nranks, int rank, const void *id128);
+int jpegx_comm_destroy(jpegx_comm_t comm);
+int jpegx_comm_gather_bytes(jpegx_comm_t comm, const void *d_send, size_t send_bytes, void *d_recv,
+                            const size_t *recv_bytes, const size_t *recv_offsets, int root,
+                            jpegx_stream_t stream);
+
 /* ---- synchronous host-pointer conveniences (H2D, kernel, D2H on an internal stream) ------ */
 int jpegx_host_forward_fused(const float *h_in, int H, int W, ptrdiff_t pitch, int mode,
                              double param, unsigned flags, int16_t *h_out);

@@ -301,3 +301,21 @@ def test_random_shapes_modes_and_values_against_oracle(gpu):
             assert gpu.entropy_encode(want) == oracle.rle_bytestream(want)
         back = gpu.inverse_fused(want, mode, param, out="f32")
         assert np.array_equal(back.astype(np.int64), oracle.inverse_i16(want, mode, param)), (trial, mode, param)
+
+
+def test_native_rccl_gather_single_rank(gpu):
+    """jpegx_comm_* on a 1-rank communicator: the gather is a send+recv to self through RCCL.  (More
+    ranks need more GPUs; the driver's multi-GPU run and tests/test_multigpu_cpu.py cover the sharding.)"""
+    from jpegx.multigpu import NativeComm
+    a = gpu.synth.generate_plane("smooth", 64, 512, seed=3)
+    zz = oracle.forward_f32(a, "qtable")
+    src, dst = gpu.DeviceBuffer(zz.nbytes), gpu.DeviceBuffer(zz.nbytes)
+    src.upload(zz)
+    gpu.check(gpu.lib().jpegx_memset(dst.ptr, 0, zz.nbytes, None))
+    comm = NativeComm(1, 0, lambda ident: ident)
+    try:
+        comm.gather_bytes(src.ptr, zz.nbytes, dst.ptr, [zz.nbytes], root=0)
+        gpu.check(gpu.lib().jpegx_device_synchronize())
+        assert np.array_equal(dst.download(zz.shape, np.int16), zz)
+    finally:
+        comm.close()
