@@ -165,7 +165,7 @@ __device__ __forceinline__ float quantise_zigzag_pack(const float (&v)[64], cons
             const float rq = prm.rq32[n];
             const float t = v[n] * rq;
             const float r = rintf(t);
-            if (!(DC_EXACT && n == 0)) worst = fmaxf(worst, fmaf(E, rq, fabsf(t - r)));
+            if (!(DC_EXACT && n == 0)) worst = fmaxf(worst, fmaf(E, fabsf(rq), fabsf(t - r)));
             q[h] = (int)r;
         }
         if (PIXEL) {
@@ -574,7 +574,7 @@ __global__ __launch_bounds__(64) void k_forward_fused_wpb(const float *__restric
         const float E = 1.5f * jpegx_fwd_err_bound(S);
         const float t = y * rq;
         float r = rintf(t);
-        bool unsafe = !(fmaf(E, rq, fabsf(t - r)) < 0.5f);
+        bool unsafe = !(fmaf(E, fabsf(rq), fabsf(t - r)) < 0.5f);
         if (DC_EXACT && lane == 0) unsafe = false;
         bool any = __any(unsafe) != 0;
         if (prm.tune & 1) any = false;

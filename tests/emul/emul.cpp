@@ -55,7 +55,7 @@ int emul_forward(const float *in, int H, int W, int mode, double param, const fl
                 if (ratio > maxratio) maxratio = ratio;
                 float t = v[n] * rq32[n];
                 float r = rintf(t);
-                float g = fmaf(E, rq32[n], fabsf(t - r));
+                float g = fmaf(E, fabsf(rq32[n]), fabsf(t - r));
                 int flag = g >= 0.5f;
                 if (dc_exact && n == 0) flag = 0;
                 int res;

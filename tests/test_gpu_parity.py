@@ -319,3 +319,41 @@ def test_native_rccl_gather_single_rank(gpu):
         assert np.array_equal(dst.download(zz.shape, np.int16), zz)
     finally:
         comm.close()
+
+
+def test_unusual_quantiser_parameters(gpu):
+    """Negative / fractional divisors (np.round(a / float(d)) accepts any float), keep = 0 and keep >= 8."""
+    a = gpu.synth.generate_plane("noise", 128, 256, seed=41)
+    for mode, param in (("divide", -3.0), ("divide", 2.5), ("divide", -64.0), ("divide", 1.0), ("divide", 1e4),
+                        ("discard", 0.0), ("discard", 8.0), ("discard", 11.0), ("discard", 1.0)):
+        want = oracle.forward_f32(a, mode, param)
+        for pixel in (True, False):
+            assert np.array_equal(gpu.forward_fused(a, mode, param, pixel_input=pixel), want), (mode, param, pixel)
+        assert np.array_equal(gpu.forward_fused(a, mode, param, flags_extra=0x800), want), (mode, param)
+        assert np.array_equal(gpu.inverse_fused(want, mode, param, out="f32").astype(np.int64),
+                              oracle.inverse_i16(want, mode, param)), (mode, param)
+
+
+def test_pooled_and_inflated_with_padded_pitches(gpu):
+    """Device entry points with pitch > width for the pooled forward and the inflated u8 inverse."""
+    L = gpu.lib()
+    h, w, bs = 32, 72, 2
+    raw = gpu.synth.generate_plane("noise", h * bs, w * bs, seed=8)
+    pitch = w * bs + 16
+    padded = np.zeros((h * bs, pitch), np.float32)
+    padded[:, :w * bs] = raw
+    din, dzz = gpu.DeviceBuffer(padded.nbytes), gpu.DeviceBuffer(h * w * 2)
+    din.upload(padded)
+    gpu.forward_fused_device(din.ptr, h, w, dzz.ptr, "qtable", 0.0, gpu.F_PIXEL_INPUT, pitch=pitch, pool=bs)
+    zz = dzz.download((h // 8, w // 8, 64), np.int16)
+    pooled = oracle.mean_pool(raw, bs).astype(np.float32)
+    want = oracle.forward_f32(pooled, "qtable")
+    assert np.array_equal(zz, want)
+    opitch = w * bs + 48
+    dout = gpu.DeviceBuffer(h * bs * opitch)
+    gpu.check(L.jpegx_memset(dout.ptr, 7, h * bs * opitch, None))
+    gpu.check(L.jpegx_inverse_fused_u8_inflated(dzz.ptr, h, w, 3, 0.0, 0, bs, dout.ptr, opitch, None))
+    got = dout.download((h * bs, opitch), np.uint8)
+    rec = np.clip(oracle.inverse_i16(want, "qtable"), 0, 255).astype(np.uint8)
+    assert np.array_equal(got[:, :w * bs], np.repeat(np.repeat(rec, bs, 0), bs, 1))
+    assert np.all(got[:, w * bs:] == 7)
