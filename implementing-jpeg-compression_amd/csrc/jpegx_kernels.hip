@@ -494,6 +494,122 @@ __global__ __launch_bounds__(64) void k_forward_fused_strip(const float *__restr
 }
 
 // ------------------------------------------------------------------------------------------------
+// fused forward on uint8 planes (the form in which image bands actually arrive: util.band_to_array,
+// util.py:110-112).  64 B (BS=1) or 256 B (BS=2, SubSampling 2x2 mean fused) are read per block
+// instead of 256 B / 1 KiB of fp32, which matters twice: the kernel's HBM traffic drops to 192 B per
+// block, and a host caller ships 4x fewer bytes over PCIe.  Same structure as k_forward_fused_strip:
+// LDS-DMA of the wave's rows, lane-per-block compute, exact tier fed from LDS, tile write-out.
+// BS=1 needs W % 16 == 0 (a 16-byte DMA chunk holds the rows of two adjacent blocks).
+// ------------------------------------------------------------------------------------------------
+template <bool DC_EXACT, int BS, bool NT>
+__global__ __launch_bounds__(64) void k_forward_fused_u8(const unsigned char *__restrict__ in, size_t pitch, int wb,
+                                                         int nblk, QuantParams prm, int16_t *__restrict__ out,
+                                                         unsigned long long *counters)
+{
+    constexpr int ROWS = 8 * BS;                       // input rows of the wave's blocks
+    constexpr int ROW_BYTES = 64 * 8 * BS;             // bytes of one input row in LDS (64 blocks)
+    constexpr int IN_BYTES = ROWS * ROW_BYTES;         // 4 KiB (BS=1) / 16 KiB (BS=2)
+    constexpr int FRONT = IN_BYTES > TILE_BYTES ? IN_BYTES : TILE_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[FRONT + SCRATCH_DOUBLES * 8 + 128];
+    double *sA = reinterpret_cast<double *>(lds + FRONT);
+    double *sM = sA + 64;
+    int16_t *sP = reinterpret_cast<int16_t *>(lds + FRONT + SCRATCH_DOUBLES * 8);
+
+    const int lane = threadIdx.x;
+    const int g0 = blockIdx.x * 64;
+    const bool valid = g0 + lane < nblk;
+
+    if (BS == 1) {
+        // piece k = rows 2k, 2k+1; lane l -> row 2k + l/32, 16-byte chunk l%32 = blocks 2c, 2c+1
+        const int c = lane & 31;
+        const int gb = min(g0 + 2 * c, nblk - 2);           // even block index inside the plane (W/8 is even)
+        const int by = gb / wb, bx = gb - by * wb;
+        const unsigned char *src = in + ((size_t)by * 8 + (lane >> 5)) * pitch + (size_t)bx * 8;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + (size_t)(2 * k) * pitch),
+                                             (__attribute__((address_space(3))) void *)(lds + k * 1024), 16, 0, NT ? 2 : 0);
+    } else {
+        // one piece per input row: lane l <-> block l (16 bytes of the row)
+        const int gb = min(g0 + lane, nblk - 1);
+        const int by = gb / wb, bx = gb - by * wb;
+        const unsigned char *src = in + ((size_t)by * 16) * pitch + (size_t)bx * 16;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + (size_t)r * pitch),
+                                             (__attribute__((address_space(3))) void *)(lds + r * 1024), 16, 0, NT ? 2 : 0);
+    }
+    __syncthreads();
+
+    float v[64];
+    if (BS == 1) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const uint2 t = *reinterpret_cast<const uint2 *>(lds + r * 512 + lane * 8);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                v[r * 8 + c] = (float)((t.x >> (8 * c)) & 0xFFu);
+                v[r * 8 + 4 + c] = (float)((t.y >> (8 * c)) & 0xFFu);
+            }
+        }
+    } else {
+        // SubSampling.execute fused (pipeline/subsampling.py:9-11): integer 2x2 sums, then * 1/4 (exact)
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const u32x4 a = *reinterpret_cast<const u32x4 *>(lds + (2 * r) * 1024 + lane * 16);
+            const u32x4 b = *reinterpret_cast<const u32x4 *>(lds + (2 * r + 1) * 1024 + lane * 16);
+            const unsigned wa[4] = {a.x, a.y, a.z, a.w}, wb2[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const unsigned x = wa[c >> 1] >> (16 * (c & 1)), y = wb2[c >> 1] >> (16 * (c & 1));
+                const unsigned sum = (x & 0xFFu) + ((x >> 8) & 0xFFu) + (y & 0xFFu) + ((y >> 8) & 0xFFu);
+                v[r * 8 + c] = (float)sum * 0.25f;
+            }
+        }
+    }
+
+    jpegx_dct8x8_f32(v);
+    const float E = jpegx_fwd_err_bound(v[0]);            // pixel input: sum|x| == DC, exact
+    unsigned pk[32];
+    const float worst = quantise_zigzag_pack<true, DC_EXACT>(v, prm, E, pk);
+
+    unsigned long long flagged = __ballot(valid && !(worst < 0.5f));
+    census(counters, flagged, nblk - g0, lane);
+    if (prm.tune & 1) flagged = 0;
+    while (flagged) {   // exact tier, samples re-read from the rows still resident in LDS
+        const int b = __ffsll((long long)flagged) - 1;
+        flagged &= flagged - 1;
+        const int i = lane >> 3, j = lane & 7;
+        double a;
+        if (BS == 1) {
+            a = (double)lds[i * 512 + b * 8 + j];
+        } else {
+            const unsigned char *p0 = lds + (2 * i) * 1024 + b * 16 + 2 * j;
+            a = ((double)p0[0] + (double)p0[1] + (double)p0[1024] + (double)p0[1025]) / 4.0;   // np.mean
+        }
+        const double y = coop_fwd_exact(a, sA, sM, lane);
+        const double r = jpegx_quant_ref(y, lane, prm.mode, prm.param, c_rq64.v);
+        sP[c_zzinv.v[lane]] = (int16_t)jpegx_clamp_i16(r);
+        __syncthreads();
+        if (lane == b) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const u32x4 t = *reinterpret_cast<const u32x4 *>(reinterpret_cast<unsigned char *>(sP) + c * 16);
+                pk[c * 4 + 0] = t.x; pk[c * 4 + 1] = t.y; pk[c * 4 + 2] = t.z; pk[c * 4 + 3] = t.w;
+            }
+        }
+        __syncthreads();
+    }
+
+    __syncthreads();    // the input rows are dead: reuse the front of LDS as the swizzled output tile
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+        *reinterpret_cast<u32x4 *>(lds + tile_off(lane, c)) = u32x4{pk[c * 4 + 0], pk[c * 4 + 1], pk[c * 4 + 2], pk[c * 4 + 3]};
+    __syncthreads();
+    store_tile<NT>(lds, out, g0, nblk, lane);
+}
+
+// ------------------------------------------------------------------------------------------------
 // fused forward, ONE WAVEFRONT PER BLOCK (the layout sketched in BASELINE.json's north_star):
 // lane = one coefficient, the strip staged in LDS, both 1-D passes as 8 per-lane FMAs fed by
 // ds_bpermute (__shfl) from the 8 lanes of the row / column, quantise + zigzag scatter into the
@@ -1218,6 +1334,34 @@ int jpegx_forward_fused(const float *d_in, int H, int W, ptrdiff_t pitch, int mo
                         int16_t *d_out, jpegx_stream_t stream)
 {
     return jpegx_forward_fused_pooled(d_in, H, W, pitch, 1, mode, param, flags, d_out, stream);
+}
+
+int jpegx_forward_fused_u8(const uint8_t *d_in, int H, int W, ptrdiff_t pitch, int bs, int mode, double param,
+                           unsigned flags, int16_t *d_out, jpegx_stream_t stream)
+{
+    if (bs != 1 && bs != 2) return fail(JPEGX_E_UNSUPPORTED, "uint8 forward supports block_size 1 and 2");
+    int rc = check_plane(d_in, d_out, H, W, pitch / bs, 1);
+    if (rc) return rc;
+    if (pitch < (ptrdiff_t)W * bs || (pitch % 16) != 0 || !aligned16(d_in) || !aligned16(d_out))
+        return fail(JPEGX_E_INVALID, "forward_u8: pitch must be a multiple of 16 bytes and >= W*bs; pointers 16-byte aligned");
+    if (bs == 1 && (W % 16) != 0) return fail(JPEGX_E_UNSUPPORTED, "forward_u8 with block_size 1 needs W to be a multiple of 16");
+    QuantParams qp;
+    rc = fill_forward_params(mode, param, &qp);
+    if (rc) return rc;
+    if (flags & JPEGX_F_TUNE_SKIP_EXACT) qp.tune |= 1;
+    const int wb = W / 8, nblk = (H / 8) * wb;
+    const dim3 grid((nblk + 63) / 64), block(64);
+    hipStream_t st = (hipStream_t)stream;
+    const bool dc_exact = is_pow2_float(qp.rq32[0]) && (qp.mode != JPEGX_Q_DIVIDE || (double)qp.rq32[0] * qp.param == 1.0);
+    const bool nt = !(flags & JPEGX_F_TUNE_NO_NT);
+#define JPEGX_LU8(DC, BSV) \
+    do { if (nt) hipLaunchKernelGGL((k_forward_fused_u8<DC, BSV, true>), grid, block, 0, st, d_in, (size_t)pitch, wb, nblk, qp, d_out, g_counters); \
+         else hipLaunchKernelGGL((k_forward_fused_u8<DC, BSV, false>), grid, block, 0, st, d_in, (size_t)pitch, wb, nblk, qp, d_out, g_counters); } while (0)
+    if (bs == 1) { if (dc_exact) JPEGX_LU8(true, 1); else JPEGX_LU8(false, 1); }
+    else { if (dc_exact) JPEGX_LU8(true, 2); else JPEGX_LU8(false, 2); }
+#undef JPEGX_LU8
+    HIP_TRY(hipGetLastError());
+    return JPEGX_OK;
 }
 
 static int inverse_common(const int16_t *d_in, int H, int W, int mode, double param, unsigned flags, void *d_out,

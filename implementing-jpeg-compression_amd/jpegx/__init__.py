@@ -68,6 +68,7 @@ SIGNATURES = {
     "jpegx_generate_plane": [_vp, _int, _int, _pd, _int, _u32, _u32, _int, _vp],
     "jpegx_forward_fused": [_vp, _int, _int, _pd, _int, _dbl, _uint, _vp, _vp],
     "jpegx_forward_fused_pooled": [_vp, _int, _int, _pd, _int, _int, _dbl, _uint, _vp, _vp],
+    "jpegx_forward_fused_u8": [_vp, _int, _int, _pd, _int, _int, _dbl, _uint, _vp, _vp],
     "jpegx_inverse_fused": [_vp, _int, _int, _int, _dbl, _uint, _vp, _pd, _int, _vp],
     "jpegx_inverse_fused_u8_inflated": [_vp, _int, _int, _int, _dbl, _uint, _int, _vp, _pd, _vp],
     "jpegx_dct8x8_f32": [_vp, _int, _int, _pd, _vp, _pd, _vp],
@@ -232,6 +233,18 @@ def forward_fused_device(in_ptr, height, width, out_ptr, mode="qtable", param=0.
                                            float(param), flags, out_ptr, stream), "jpegx_forward_fused")
 
 
+def forward_fused_u8_device(in_ptr, height, width, out_ptr, mode="qtable", param=0.0, flags=0, pitch=None,
+                            pool=1, stream=None):
+    """Enqueue steps (1+)4+5+6 on a uint8 device plane of (height*pool, width*pool) bytes."""
+    check(lib().jpegx_forward_fused_u8(in_ptr, height, width, pitch or width * pool, pool, mode_of(mode),
+                                       float(param), flags, out_ptr, stream), "jpegx_forward_fused_u8")
+
+
+def u8_path_ok(width_out, pool, pitch_bytes):
+    """Shapes the uint8 kernels accept: block_size 1 (W % 16 == 0) or 2, 16-byte aligned rows."""
+    return pool in (1, 2) and pitch_bytes % 16 == 0 and (pool == 2 or width_out % 16 == 0)
+
+
 def inverse_fused_device(in_ptr, height, width, out_ptr, mode="qtable", param=0.0, flags=0, out_type=OUT_F32,
                          out_pitch=None, stream=None):
     check(lib().jpegx_inverse_fused(in_ptr, height, width, mode_of(mode), float(param), flags, out_ptr,
@@ -288,6 +301,25 @@ def forward_fused_pooled(plane, block_size, mode="qtable", param=0.0, pixel_inpu
         din.upload(a)
         forward_fused_device(din.ptr, h, w, dout.ptr, mode, param, F_PIXEL_INPUT if pixel_input else 0,
                              pitch=ww, pool=bs)
+        return dout.download(out.shape, np.int16)
+    finally:
+        din.free()
+        dout.free()
+
+
+def forward_fused_u8(plane, block_size=1, mode="qtable", param=0.0, flags_extra=0):
+    """uint8 plane (H*bs, W*bs) -> int16 (H/8, W/8, 64): SubSampling (bs=2) + steps 4-6, 4x less PCIe."""
+    a = _plane(plane, np.uint8)
+    bs = int(block_size)
+    hh, ww = a.shape
+    if hh % (8 * bs) or ww % (8 * bs):
+        raise JpegxError("plane must be a multiple of 8*block_size in both dimensions")
+    h, w = hh // bs, ww // bs
+    out = np.empty((h // 8, w // 8, 64), dtype=np.int16)
+    din, dout = DeviceBuffer(a.nbytes), DeviceBuffer(out.nbytes)
+    try:
+        din.upload(a)
+        forward_fused_u8_device(din.ptr, h, w, dout.ptr, mode, param, flags_extra, pitch=ww, pool=bs)
         return dout.download(out.shape, np.int16)
     finally:
         din.free()
@@ -413,21 +445,29 @@ def entropy_encode(zz):
 def compress_plane(plane, block_size=1, mode="qtable", param=0.0):
     """Steps 1-8 of the codec for one (already padded) plane with everything on the device:
     fused mean-pool + DCT + quantise + zigzag, then the entropy stage; only the final bytes come back."""
-    a = _plane(plane, np.float32)
+    src = np.asarray(plane)
     bs = int(block_size)
-    hh, ww = a.shape
+    if src.ndim != 2:
+        raise JpegxError("expected a 2-D plane, got shape %r" % (src.shape,))
+    hh, ww = src.shape
     if hh % (8 * bs) or ww % (8 * bs):
         raise JpegxError("plane must be a multiple of 8*block_size in both dimensions")
     h, w = hh // bs, ww // bs
     nblocks = (h // 8) * (w // 8)
+    as_u8 = (src.dtype == np.uint8 or (src.dtype.kind in "ui" and src.size and src.min() >= 0 and src.max() <= 255)) \
+        and u8_path_ok(w, bs, ww)
+    a = np.ascontiguousarray(src, dtype=np.uint8 if as_u8 else np.float32)
     L = lib()
     din, dzz = DeviceBuffer(a.nbytes), DeviceBuffer(h * w * 2)
     dws = DeviceBuffer(L.jpegx_entropy_workspace_bytes(nblocks))
     dout = None
     try:
         din.upload(a)
-        forward_fused_device(din.ptr, h, w, dzz.ptr, mode, param, F_PIXEL_INPUT if is_pixel_like(a) else 0,
-                             pitch=ww, pool=bs)
+        if as_u8:
+            forward_fused_u8_device(din.ptr, h, w, dzz.ptr, mode, param, 0, pitch=ww, pool=bs)
+        else:
+            forward_fused_device(din.ptr, h, w, dzz.ptr, mode, param, F_PIXEL_INPUT if is_pixel_like(a) else 0,
+                                 pitch=ww, pool=bs)
         check(L.jpegx_entropy_sizes(dzz.ptr, nblocks, dws.ptr, None), "jpegx_entropy_sizes")
         total = ctypes.c_ulonglong(0)
         check(L.jpegx_entropy_total(dws.ptr, ctypes.byref(total), None), "jpegx_entropy_total")

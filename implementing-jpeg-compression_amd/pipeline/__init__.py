@@ -142,7 +142,7 @@ def _front_end_fused(band, config, with_entropy):
     import jpegx
     mode, param = config.quantization.gpu_mode()
     if with_entropy:
-        return jpegx.compress_plane(padded.astype(np.float32), bs, mode, param)
+        return jpegx.compress_plane(padded, bs, mode, param)      # uint8 upload when the shape allows
     return jpegx.forward_fused_pooled(padded.astype(np.float32), bs, mode, param, pixel_input=True).astype(np.float64)
 
 

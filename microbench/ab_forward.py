@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--direction", default="forward", choices=["forward", "inverse"])
     ap.add_argument("--out-type", default="f32")
     ap.add_argument("--pool", type=int, default=1, help="forward: fused mean-pool factor (input is pool x larger)")
+    ap.add_argument("--u8", action="store_true", help="forward: uint8 input planes (jpegx_forward_fused_u8)")
     a = ap.parse_args()
     jpegx.require_device()
     L = jpegx.lib()
@@ -39,13 +40,23 @@ def main():
     for p in range(planes):
         jpegx.generate_plane_device(plane_buf.ptr + p * size * size * 4 * pool * pool, size * pool, size * pool,
                                     a.kind, seed=0, plane=p)
+    u8_buf = None
+    if a.u8:
+        import numpy as np
+        u8_buf = jpegx.DeviceBuffer(H * W * pool * pool)
+        rows = 512                                      # convert on the host in slabs (setup only)
+        for y0 in range(0, H * pool, rows):
+            slab = plane_buf.download((rows, W * pool), np.float32, offset=y0 * W * pool * 4).astype(np.uint8)
+            u8_buf.upload(slab, offset=y0 * W * pool)
     jpegx.forward_fused_device(plane_buf.ptr, H, W, zz_buf.ptr, "qtable", 0.0, jpegx.F_PIXEL_INPUT, pool=pool)
     jpegx.check(L.jpegx_device_synchronize())
     variants = [(v.split("=")[0], int(v.split("=")[1], 0)) for v in a.variants]
     ot = {"f32": 0, "i16": 1, "u8": 2}[a.out_type]
 
     def launch(flags):
-        if a.direction == "forward":
+        if a.direction == "forward" and a.u8:
+            jpegx.forward_fused_u8_device(u8_buf.ptr, H, W, zz_buf.ptr, "qtable", 0.0, flags & ~1, pool=pool)
+        elif a.direction == "forward":
             jpegx.forward_fused_device(plane_buf.ptr, H, W, zz_buf.ptr, "qtable", 0.0, flags, pool=pool)
         else:
             jpegx.inverse_fused_device(zz_buf.ptr, H, W, plane_buf.ptr, "qtable", 0.0, flags, out_type=ot)
@@ -66,7 +77,7 @@ def main():
     for n, f in variants:
         med, mn = statistics.median(times[n]), min(times[n])
         if a.direction == "forward":
-            bpb = 256 * pool * pool + 128
+            bpb = (64 if a.u8 else 256) * pool * pool + 128
         else:
             bpb = 128 + {"f32": 256, "i16": 128, "u8": 64}[a.out_type]
         print("%-12s flags=0x%03x  median %.4f ms  min %.4f ms  %.1f GB/s (median, %d B/block)  %.1f Mblocks/s"
