@@ -50,6 +50,8 @@ def lib():
         L.jo_unzigzag_plane.argtypes = [dp, c_int, c_int, dp]
         L.jo_forward_f32.argtypes = [ctypes.POINTER(ctypes.c_float), c_int, c_int, c_pd, c_int, c_dbl,
                                      ctypes.POINTER(ctypes.c_int16), dp]
+        L.jo_forward_f32_mt.argtypes = [ctypes.POINTER(ctypes.c_float), c_int, c_int, c_pd, c_int, c_dbl,
+                                        ctypes.POINTER(ctypes.c_int16), c_int]
         L.jo_inverse_i16.argtypes = [ctypes.POINTER(ctypes.c_int16), c_int, c_int, c_int, c_dbl,
                                      ctypes.POINTER(ctypes.c_int32), dp]
         L.jo_mean_pool.argtypes = [dp, c_int, c_int, c_int, dp]
@@ -160,6 +162,16 @@ def forward_f32(plane, mode, param=0.0, want_dct=False):
                                 _p(zz, ctypes.c_int16),
                                 _p(dct, ctypes.c_double) if want_dct else None), "forward_f32")
     return (zz, dct) if want_dct else zz
+
+
+def forward_f32_mt(plane, mode, param=0.0, threads=1):
+    """forward_f32 with the block rows spread over OpenMP threads (identical output)."""
+    a = np.ascontiguousarray(plane, dtype=np.float32)
+    h, w = a.shape
+    zz = np.empty((h // 8, w // 8, 64), dtype=np.int16)
+    _check(lib().jo_forward_f32_mt(_p(a, ctypes.c_float), h, w, w, _mode(mode), float(param),
+                                   _p(zz, ctypes.c_int16), int(threads)), "forward_f32_mt")
+    return zz
 
 
 def inverse_i16(zz, mode, param=0.0, want_float=False):
