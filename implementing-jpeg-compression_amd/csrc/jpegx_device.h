@@ -1,0 +1,198 @@
+// jpegx_device.h -- device-side building blocks shared by the kernel translation units of
+// libjpegx.so: the reference's constant tables, the by-value quantiser parameters, cache-policy
+// load/store helpers, the XOR-swizzled LDS tile, the cooperative float64 exact tier and the
+// quantise/pack + tile write-out helpers of the forward kernels.  Everything lives in an anonymous
+// namespace (each translation unit gets its own copy; nothing here is exported).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/jpegx.h"
+#include "jpegx_math.h"
+
+// ------------------------------------------------------------------------------------------------
+// constant tables (reference data, include/jpegx_tables.inc)
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+struct D64 { double v[64]; };
+struct I64 { int v[64]; };
+
+constexpr I64 make_zz() { return I64{{JPEGX_TABLE_ZIGZAG8}}; }
+constexpr I64 make_zzinv()
+{
+    I64 z = make_zz(), r{};
+    for (int p = 0; p < 64; ++p) r.v[z.v[p]] = p;
+    return r;
+}
+constexpr I64 make_qt() { return I64{{JPEGX_TABLE_QTABLE}}; }
+constexpr D64 make_rq64()
+{
+    I64 q = make_qt();
+    D64 r{};
+    for (int n = 0; n < 64; ++n) r.v[n] = 1.0 / (double)q.v[n];  // quantizers.py:49 "1.0 / q"
+    return r;
+}
+
+constexpr I64 kZZ = make_zz();        // zigzag position p -> natural index n = i*8+j
+constexpr I64 kQT = make_qt();
+
+__device__ const double c_dct[64] = {JPEGX_TABLE_DCT_MATRIX};     // C[k][n]
+__device__ const double c_cn[64] = {JPEGX_TABLE_DCT_NORMALIZED};  // Cn[k][n]
+__device__ const double c_dinv[8] = {JPEGX_TABLE_NORM_DIAG};
+__device__ const D64 c_rq64 = make_rq64();
+__device__ const I64 c_qt = make_qt();
+__device__ const I64 c_zz = make_zz();
+__device__ const I64 c_zzinv = make_zzinv();
+
+// by-value kernel parameters of the fused kernels (land in SGPRs through the kernarg segment)
+struct QuantParams {
+    float rq32[64];  // forward: fp32 reciprocal per natural index (0 = discarded coefficient)
+                     // inverse: fp32 multiplier per natural index
+    double param;    // keep / divisor
+    int mode;
+    int tune;        // bit0: skip the exact tier (timing experiments only -- results are then NOT bit-exact)
+};
+
+// LDS tile of one wave: 64 rows (blocks) x 128 B, 16-B chunks XOR-swizzled by the row so that
+// both the per-lane row writes and the linear read-out are bank-conflict free.
+__device__ __forceinline__ int tile_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
+
+// 16-byte global accesses with a selectable cache policy.  NT = nontemporal ("nt" bit): the
+// planes and the coefficient stream are touched exactly once, so they should not displace
+// each other in L2/MALL; on MI355X a 2:1 read:write stream runs ~10 % faster with nt
+// (microbench/membench.hip: 5.7 -> 6.3 TB/s).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+template <bool NT> __device__ __forceinline__ f32x4 ld_f32x4(const float *p)
+{
+    return NT ? __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(p)) : *reinterpret_cast<const f32x4 *>(p);
+}
+template <bool NT> __device__ __forceinline__ u32x4 ld_u32x4(const void *p)
+{
+    return NT ? __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p)) : *reinterpret_cast<const u32x4 *>(p);
+}
+template <bool NT> __device__ __forceinline__ void st_u32x4(void *p, u32x4 v)
+{
+    if (NT) __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(p)); else *reinterpret_cast<u32x4 *>(p) = v;
+}
+template <bool NT> __device__ __forceinline__ void st_f32x4(float *p, f32x4 v)
+{
+    if (NT) __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(p)); else *reinterpret_cast<f32x4 *>(p) = v;
+}
+template <bool NT> __device__ __forceinline__ void st_u32x2(void *p, u32x2 v)
+{
+    if (NT) __builtin_nontemporal_store(v, reinterpret_cast<u32x2 *>(p)); else *reinterpret_cast<u32x2 *>(p) = v;
+}
+
+constexpr int TILE_BYTES = 64 * 128;
+constexpr int SCRATCH_DOUBLES = 128;  // sA[64] + sM[64]
+constexpr int LDS_BYTES = TILE_BYTES + SCRATCH_DOUBLES * 8;
+
+// ------------------------------------------------------------------------------------------------
+// float64 exact tier, cooperative: the wave computes ONE block, lane = one matrix element.
+// ------------------------------------------------------------------------------------------------
+
+// forward: lane = i*8+j passes A[i][j]; returns Y[k][l] for lane = k*8+l.
+// transforms.py:46-58 (rows then columns) in the reference's dgemv order (jpegx_dot8_ref).
+__device__ __forceinline__ double coop_fwd_exact(double a_own, double *sA, double *sM, int lane)
+{
+    const int hi = lane >> 3, lo = lane & 7;
+    sA[lane] = a_own;
+    __syncthreads();
+    const double m = jpegx_dot8_ref(&c_dct[lo * 8], &sA[hi * 8], 1);  // M[i=hi][l=lo]
+    sM[lo * 8 + hi] = m;                                              // column l contiguous over i
+    __syncthreads();
+    const double y = jpegx_dot8_ref(&c_dct[hi * 8], &sM[lo * 8], 1);  // Y[k=hi][l=lo]
+    __syncthreads();
+    return y;
+}
+
+// inverse: lane = k*8+j passes Z[k][j]; returns x[i][j] for lane = i*8+j (float, not rounded).
+// transforms.py:60-69 (columns then rows), transform_1d_inverse order (jpegx_idot8_ref).
+__device__ __forceinline__ double coop_inv_exact(double z_own, double *sA, double *sM, int lane)
+{
+    const int hi = lane >> 3, lo = lane & 7;
+    double w[8];
+    sA[lo * 8 + hi] = c_dinv[hi] * z_own;  // u[k] of column j, stored [j][k]
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) w[k] = c_cn[k * 8 + hi];
+    const double m = jpegx_idot8_ref(w, &sA[lo * 8], 1);  // m[i=hi][j=lo]
+    sM[hi * 8 + lo] = c_dinv[lo] * m;                     // u[k=lo] of row i
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) w[k] = c_cn[k * 8 + lo];
+    const double y = jpegx_idot8_ref(w, &sM[hi * 8], 1);  // x[i=hi][j=lo]
+    __syncthreads();
+    return y;
+}
+
+// ------------------------------------------------------------------------------------------------
+// pieces shared by the forward kernels
+// ------------------------------------------------------------------------------------------------
+
+// Quantise the 64 coefficients of v (natural order) in zigzag order and pack them as int16 pairs
+// (pipeline/quantization.py:8-18 + pipeline/zigzag_order.py:85-99; the zigzag is a compile-time
+// renaming).  Returns the worst rounding margin max(|t - rint(t)| + E / q): the block is safe iff
+// it stays below 1/2.  PIXEL: values provably fit int16, no saturation needed.
+template <bool PIXEL, bool DC_EXACT>
+__device__ __forceinline__ float quantise_zigzag_pack(const float (&v)[64], const QuantParams &prm, float E,
+                                                      unsigned (&pk)[32])
+{
+    float worst = 0.f;
+#pragma unroll
+    for (int p = 0; p < 64; p += 2) {
+        int q[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int n = kZZ.v[p + h];
+            const float rq = prm.rq32[n];
+            const float t = v[n] * rq;
+            const float r = rintf(t);
+            if (!(DC_EXACT && n == 0)) worst = fmaxf(worst, fmaf(E, fabsf(rq), fabsf(t - r)));
+            q[h] = (int)r;
+        }
+        if (PIXEL) {
+            pk[p >> 1] = ((unsigned)q[0] & 0xFFFFu) | ((unsigned)q[1] << 16);
+        } else {
+            const int a = min(max(q[0], -32768), 32767), b = min(max(q[1], -32768), 32767);
+            pk[p >> 1] = ((unsigned)a & 0xFFFFu) | ((unsigned)b << 16);
+        }
+    }
+    return worst;
+}
+
+// The wave's 64 x 128 B output tile -> 8 coalesced 1 KiB stores into the zigzag stream.
+template <bool NT>
+__device__ __forceinline__ void store_tile(const unsigned char *tile, int16_t *out, int g0, int nblk, int lane)
+{
+    unsigned char *dst = reinterpret_cast<unsigned char *>(out) + (size_t)g0 * 128;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int row = i * 8 + (lane >> 3), c = lane & 7;
+        const u32x4 q = *reinterpret_cast<const u32x4 *>(tile + tile_off(row, c));
+        if (g0 + row < nblk) st_u32x4<NT>(dst + (size_t)row * 128 + c * 16, q);
+    }
+}
+
+// exact-tier census (jpegx_set_debug_counters): [0] += flagged blocks, [1] += blocks of this wave
+__device__ __forceinline__ void census(unsigned long long *counters, unsigned long long flagged, int remaining, int lane)
+{
+    if (counters != nullptr && lane == 0) {
+        atomicAdd(&counters[0], (unsigned long long)__popcll(flagged));
+        atomicAdd(&counters[1], (unsigned long long)min(64, remaining));
+    }
+}
+
+// chunk permutation of the forward strip / inverse output strip: 16-B chunk c of a 2 KiB row sits at
+// slot c ^ (bit3(c) ^ bit4(c)), which makes a ds_read_b128 / ds_write_b128 at a 32-byte lane stride
+// bank-conflict free
+__device__ __forceinline__ int strip_swz(int chunk) { return chunk ^ (((chunk >> 3) ^ (chunk >> 4)) & 1); }
+
+constexpr int STRIP_BYTES = 8 * 2048;
+constexpr int STRIP_LDS_BYTES = STRIP_BYTES + SCRATCH_DOUBLES * 8 + 128;
+
+}  // namespace

@@ -23,7 +23,7 @@
 
 #include "../../include/jpegx.h"
 
-extern "C" void jpegx_internal_set_error(const char *msg);  // jpegx_kernels.hip (thread-local string)
+extern "C" void jpegx_internal_set_error(const char *msg);  // jpegx_runtime.hip (thread-local string)
 
 namespace {
 

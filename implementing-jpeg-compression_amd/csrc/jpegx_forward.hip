@@ -1,0 +1,645 @@
+// jpegx_forward.hip -- gfx950 (MI355X, CDNA4) fused forward kernels + their C ABI entries (libjpegx.so).
+//
+// Work decomposition of the fused kernels ("lane-per-block, strip-per-wave"):
+//   * a wavefront (64 lanes) owns 64 consecutive 8x8 blocks of the block-row-major block
+//     order (pipeline/base.py:58-66: y outer, x inner); lane b holds ALL 64 samples of block
+//     g0+b in registers, so both 1-D DCT passes, the quantiser and the zigzag permutation
+//     are register-only -- no cross-lane traffic, the zigzag is a compile-time renaming and
+//     the quantiser constants sit in SGPRs;
+//   * the wave's 64 output blocks are one contiguous 8 KiB span of the zigzag stream: each
+//     lane parks its 128 B in an XOR-swizzled LDS tile and the wave writes the tile back
+//     with 1 KiB-per-instruction fully coalesced stores;
+//   * exact tier: a lane whose block has a coefficient within the fp32 error bound of a
+//     rounding boundary raises a flag; the wave then recomputes each flagged block
+//     cooperatively in float64 in the reference's operation order (lane = one coefficient,
+//     two LDS exchanges) and patches the tile.  See jpegx_math.h / DESIGN.md.
+////
+// This file: the fused forward kernels (fp32 strip kernel = default, per-lane / LDS-staged pooled
+// variants, uint8 input, the one-wavefront-per-block comparison variant) and their C entry points.
+// Built with: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (explicit fma only).
+#include "jpegx_internal.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// fused forward: DCT + quantise + zigzag.  VAR bit0 = PIXEL_INPUT, bit1 = DC exact.
+// BS = mean-pool factor of the fused SubSampling prologue (1 = none).
+// ------------------------------------------------------------------------------------------------
+template <int VAR, int BS, bool NT, int STAGED>
+__global__ __launch_bounds__(64) void k_forward_fused(const float *__restrict__ in, size_t pitch, int wb,
+                                                      int nblk, QuantParams prm, int16_t *__restrict__ out,
+                                                      unsigned long long *counters)
+{
+    constexpr bool PIXEL = (VAR & 1) != 0;
+    constexpr bool DC_EXACT = (VAR & 2) != 0;
+    constexpr int STAGE_BYTES = STAGED * 2 * BS * 1024;                 // staging buffer (0 if not staged)
+    constexpr int FRONT = STAGE_BYTES > TILE_BYTES ? STAGE_BYTES : TILE_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[FRONT + SCRATCH_DOUBLES * 8];
+    double *sA = reinterpret_cast<double *>(lds + FRONT);
+    double *sM = sA + 64;
+
+    const int lane = threadIdx.x;
+    const int g0 = blockIdx.x * 64;
+    const int g = g0 + lane;
+    const bool valid = g < nblk;
+    const int gc = valid ? g : nblk - 1;
+    const int by = gc / wb, bx = gc - by * wb;
+    const float *src = in + ((size_t)by * 8 * BS) * pitch + (size_t)bx * 8 * BS;
+
+    float v[64];
+    if (BS == 1) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const float *row = src + (size_t)r * pitch;
+            const f32x4 lo = ld_f32x4<NT>(row), hi = ld_f32x4<NT>(row + 4);
+            v[r * 8 + 0] = lo.x; v[r * 8 + 1] = lo.y; v[r * 8 + 2] = lo.z; v[r * 8 + 3] = lo.w;
+            v[r * 8 + 4] = hi.x; v[r * 8 + 5] = hi.y; v[r * 8 + 6] = hi.z; v[r * 8 + 7] = hi.w;
+        }
+    } else if (STAGED) {
+        // SubSampling.execute fused (pipeline/subsampling.py:9-11), input staged through LDS: the
+        // wave's 64 blocks cover 8*BS input rows of 64 * 32*BS bytes; they are streamed in phases of
+        // 8 KiB (BS=2: two input rows = one output row; BS=4: one input row) by LDS-DMA -- whole
+        // 128-B lines, nontemporal -- and every lane folds its 2*BS chunks per row into the 8 pooled
+        // samples of the output row.  Chunk q of block b sits at slot 2BS*b + (q ^ g(b)),
+        // g(b) = (b >> (BS == 2 ? 2 : 1)) & (2BS - 1): conflict-free ds_read_b128 at a 32*BS-byte
+        // lane stride; the permutation is applied on the DMA source address.
+        constexpr int CPB = 2 * BS;                 // 16-B chunks per block and input row
+        constexpr int RPP = STAGED;                 // input rows per phase (RPP * CPB KiB of LDS)
+        constexpr int GSH = (BS == 2) ? 2 : 1;
+        // per-lane 32-bit byte offsets from the wave's first block (keeps the DMA addresses in the
+        // "scalar base + vector offset" form: the row advance is scalar arithmetic)
+        const int by0 = g0 / wb, bx0 = g0 - by0 * wb;
+        const unsigned char *base0 = reinterpret_cast<const unsigned char *>(in + ((size_t)by0 * 8 * BS) * pitch + (size_t)bx0 * 8 * BS);
+        unsigned off[CPB];
+#pragma unroll
+        for (int j = 0; j < CPB; ++j) {
+            const int slot = 64 * j + lane;
+            const int b = slot / CPB, sl = slot % CPB;
+            const int q = sl ^ ((b >> GSH) & (CPB - 1));
+            const int gb = min(g0 + b, nblk - 1);
+            const int byb = gb / wb, bxb = gb - byb * wb;
+            off[j] = (unsigned)(((size_t)(byb - by0) * 8 * BS * pitch + ((size_t)bxb - bx0) * 8 * BS + q * 4) * 4);
+        }
+        const int gq = (lane >> GSH) & (CPB - 1);
+        float acc[8];
+#pragma unroll
+        for (int ph = 0; ph < 8 * BS / RPP; ++ph) {
+            __syncthreads();                        // previous phase's LDS reads are done
+#pragma unroll
+            for (int rr = 0; rr < RPP; ++rr) {
+                const unsigned char *rowbase = base0 + (size_t)(ph * RPP + rr) * pitch * 4;
+#pragma unroll
+                for (int j = 0; j < CPB; ++j)
+                    __builtin_amdgcn_global_load_lds(
+                        (const __attribute__((address_space(1))) void *)(rowbase + off[j]),
+                        (__attribute__((address_space(3))) void *)(lds + (rr * CPB + j) * 1024), 16, 0, NT ? 2 : 0);
+            }
+            __syncthreads();                        // drains vmcnt: the phase has landed
+#pragma unroll
+            for (int rr = 0; rr < RPP; ++rr) {
+                const int ir = ph * RPP + rr, r = ir / BS, a = ir % BS;
+                if (a == 0) {
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) acc[c] = 0.f;
+                }
+#pragma unroll
+                for (int q = 0; q < CPB; ++q) {
+                    const f32x4 t = *reinterpret_cast<const f32x4 *>(lds + rr * CPB * 1024 + ((CPB * lane + (q ^ gq)) << 4));
+                    const float e[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+                    for (int s2 = 0; s2 < 4; ++s2) acc[(q * 4 + s2) / BS] += e[s2];
+                }
+                if (a == BS - 1) {
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        v[r * 8 + c] = acc[c] * (1.0f / (BS * BS));
+                        // pin the pooled value here: without it hipcc sinks all the adds below the last
+                        // phase and keeps every raw chunk live (178 VGPRs, 2 waves/SIMD)
+                        asm volatile("" : "+v"(v[r * 8 + c]) : : "memory");
+                    }
+                }
+            }
+        }
+        __syncthreads();                            // the staging buffer becomes the output tile
+    } else {
+        // SubSampling.execute fused (pipeline/subsampling.py:9-11): BS x BS mean, exact in fp32
+        // for 8-bit samples (sum < 2^24, 1/BS^2 a power of two).
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            float acc[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) acc[c] = 0.f;
+#pragma unroll
+            for (int a = 0; a < BS; ++a) {
+                const float *row = src + (size_t)(r * BS + a) * pitch;
+#pragma unroll
+                for (int q = 0; q < 2 * BS; ++q) {
+                    const f32x4 t = ld_f32x4<NT>(row + 4 * q);
+                    const float e[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) acc[(q * 4 + s) / BS] += e[s];
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                v[r * 8 + c] = acc[c] * (1.0f / (BS * BS));
+                asm volatile("" : "+v"(v[r * 8 + c]) : : "memory");   // fold now, do not keep raw samples live
+            }
+        }
+    }
+
+    float S = 0.f;
+    if (!PIXEL) {
+#pragma unroll
+        for (int n = 0; n < 64; ++n) S += fabsf(v[n]);
+    }
+    jpegx_dct8x8_f32(v);
+    if (PIXEL) S = v[0];  // non-negative samples: sum|x| == DC, exact
+    // generic pooled input: the fp32 tile sums are themselves rounded (<= BS^2 u each)
+    const float E = jpegx_fwd_err_bound(S) * ((PIXEL || BS == 1) ? 1.0f : 1.0f + (BS * BS) / 16.0f);
+
+    // quantise in zigzag order, pack pairs, track the worst rounding margin
+    unsigned pk[32];
+    const float worst = quantise_zigzag_pack<PIXEL, DC_EXACT>(v, prm, E, pk);
+
+    // park the lane's 128 B in the swizzled tile
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+        *reinterpret_cast<uint4 *>(lds + tile_off(lane, c)) =
+            make_uint4(pk[c * 4 + 0], pk[c * 4 + 1], pk[c * 4 + 2], pk[c * 4 + 3]);
+
+    // exact tier for blocks that sit within the error bound of a rounding boundary
+    unsigned long long flagged = __ballot(valid && !(worst < 0.5f));
+    census(counters, flagged, nblk - g0, lane);
+    if (prm.tune & 1) flagged = 0;
+    __syncthreads();
+    while (flagged) {
+        const int b = __ffsll((long long)flagged) - 1;
+        flagged &= flagged - 1;
+        const int gb = g0 + b;
+        const int byb = gb / wb, bxb = gb - byb * wb;
+        const int i = lane >> 3, j = lane & 7;
+        const float *p = in + ((size_t)(byb * 8 + i) * BS) * pitch + (size_t)(bxb * 8 + j) * BS;
+        double a;
+        if (BS == 1) {
+            a = (double)p[0];
+        } else {
+            double s = 0.0;  // np.mean: float64 sum then one division (subsampling.py:11)
+#pragma unroll
+            for (int u = 0; u < BS; ++u)
+#pragma unroll
+                for (int w = 0; w < BS; ++w) s += (double)p[(size_t)u * pitch + w];
+            a = s / (double)(BS * BS);
+        }
+        const double y = coop_fwd_exact(a, sA, sM, lane);
+        const double r = jpegx_quant_ref(y, lane, prm.mode, prm.param, c_rq64.v);
+        const int pz = c_zzinv.v[lane];
+        *reinterpret_cast<int16_t *>(lds + tile_off(b, pz >> 3) + (pz & 7) * 2) = (int16_t)jpegx_clamp_i16(r);
+    }
+    __syncthreads();
+
+    // coalesced write-back: 8 x 1 KiB per wave
+    store_tile<NT>(lds, out, g0, nblk, lane);
+}
+
+// ------------------------------------------------------------------------------------------------
+// fused forward, LDS-staged input (the default kernel).  The wave's 64 blocks -- when W/8 is a
+// multiple of 64, one 8-row x 2 KiB strip of the plane -- are brought in by LDS-DMA
+// (global_load_lds_dwordx4: 16 pieces of 1 KiB, whole-128-B-line requests, no VGPR staging)
+// and each lane then picks its own block out of LDS.  Compared with per-lane global loads
+// (k_forward_fused: 16 B at a 32 B lane stride, every line touched by two instructions) this
+// reads each line exactly once, which is what lets the nontemporal policy pay off:
+// 5.6 -> 6.5 TB/s on MI355X (profiles/).  16-B chunks of a row are
+// stored at position c ^ f(c >> 1), f(b) = bit2(b) ^ bit3(b), which makes the per-lane
+// ds_read_b128 (lane stride 32 B) bank-conflict free; the permutation is applied on the DMA
+// SOURCE address because the DMA's LDS destination is always base + lane * 16.
+// After the compute the dead strip is reused as the output tile.
+// ------------------------------------------------------------------------------------------------
+template <int VAR, bool NT>
+__global__ __launch_bounds__(64) void k_forward_fused_strip(const float *__restrict__ in, size_t pitch, int wb,
+                                                            int nblk, QuantParams prm, int16_t *__restrict__ out,
+                                                            unsigned long long *counters)
+{
+    constexpr bool PIXEL = (VAR & 1) != 0;
+    constexpr bool DC_EXACT = (VAR & 2) != 0;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[STRIP_LDS_BYTES];
+    double *sA = reinterpret_cast<double *>(lds + STRIP_BYTES);
+    double *sM = sA + 64;
+    int16_t *sP = reinterpret_cast<int16_t *>(lds + STRIP_BYTES + SCRATCH_DOUBLES * 8);
+
+    const int lane = threadIdx.x;
+    const int g0 = blockIdx.x * 64;
+    const bool valid = g0 + lane < nblk;
+
+    // 16 DMA pieces of 1 KiB: piece (r, j) fills LDS bytes [r*2048 + j*1024, +1024); lane l of
+    // piece j fills chunk slot p = 64 j + l of the row, which holds chunk c = strip_swz(p) =
+    // half (c & 1) of block c >> 1.  Blocks past the end of the plane re-read the last block.
+    {
+        const float *src[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int c = strip_swz(64 * j + lane);
+            const int gb = min(g0 + (c >> 1), nblk - 1);
+            const int by = gb / wb, bx = gb - by * wb;
+            src[j] = in + (size_t)by * 8 * pitch + (size_t)bx * 8 + (c & 1) * 4;
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src[0] + (size_t)r * pitch),
+                                             (__attribute__((address_space(3))) void *)(lds + r * 2048), 16, 0, NT ? 2 : 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src[1] + (size_t)r * pitch),
+                                             (__attribute__((address_space(3))) void *)(lds + r * 2048 + 1024), 16, 0, NT ? 2 : 0);
+        }
+    }
+    __syncthreads();  // drains vmcnt: the strip has landed
+
+    float v[64];
+    {
+        const int f = ((lane >> 2) ^ (lane >> 3)) & 1;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const f32x4 lo = *reinterpret_cast<const f32x4 *>(lds + r * 2048 + ((2 * lane + f) << 4));
+            const f32x4 hi = *reinterpret_cast<const f32x4 *>(lds + r * 2048 + ((2 * lane + (f ^ 1)) << 4));
+            v[r * 8 + 0] = lo.x; v[r * 8 + 1] = lo.y; v[r * 8 + 2] = lo.z; v[r * 8 + 3] = lo.w;
+            v[r * 8 + 4] = hi.x; v[r * 8 + 5] = hi.y; v[r * 8 + 6] = hi.z; v[r * 8 + 7] = hi.w;
+        }
+    }
+
+    float S = 0.f;
+    if (!PIXEL) {
+#pragma unroll
+        for (int n = 0; n < 64; ++n) S += fabsf(v[n]);
+    }
+    jpegx_dct8x8_f32(v);
+    if (PIXEL) S = v[0];
+    const float E = jpegx_fwd_err_bound(S);
+
+    unsigned pk[32];
+    const float worst = quantise_zigzag_pack<PIXEL, DC_EXACT>(v, prm, E, pk);
+
+    unsigned long long flagged = __ballot(valid && !(worst < 0.5f));
+    census(counters, flagged, nblk - g0, lane);
+    if (prm.tune & 1) flagged = 0;
+    while (flagged) {   // exact tier, inputs re-read from the strip still resident in LDS
+        const int b = __ffsll((long long)flagged) - 1;
+        flagged &= flagged - 1;
+        const int i = lane >> 3, j = lane & 7;
+        const int fb = ((b >> 2) ^ (b >> 3)) & 1;
+        const float x = *reinterpret_cast<const float *>(lds + i * 2048 + ((2 * b + ((j >> 2) ^ fb)) << 4) + (j & 3) * 4);
+        const double y = coop_fwd_exact((double)x, sA, sM, lane);
+        const double r = jpegx_quant_ref(y, lane, prm.mode, prm.param, c_rq64.v);
+        sP[c_zzinv.v[lane]] = (int16_t)jpegx_clamp_i16(r);
+        __syncthreads();
+        if (lane == b) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const u32x4 t = *reinterpret_cast<const u32x4 *>(reinterpret_cast<unsigned char *>(sP) + c * 16);
+                pk[c * 4 + 0] = t.x; pk[c * 4 + 1] = t.y; pk[c * 4 + 2] = t.z; pk[c * 4 + 3] = t.w;
+            }
+        }
+        __syncthreads();
+    }
+
+    // the strip is dead: reuse its first 8 KiB as the swizzled output tile
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+        *reinterpret_cast<u32x4 *>(lds + tile_off(lane, c)) = u32x4{pk[c * 4 + 0], pk[c * 4 + 1], pk[c * 4 + 2], pk[c * 4 + 3]};
+    __syncthreads();
+    store_tile<NT>(lds, out, g0, nblk, lane);
+}
+
+// ------------------------------------------------------------------------------------------------
+// fused forward on uint8 planes (the form in which image bands actually arrive: util.band_to_array,
+// util.py:110-112).  64 B (BS=1) or 256 B (BS=2, SubSampling 2x2 mean fused) are read per block
+// instead of 256 B / 1 KiB of fp32, which matters twice: the kernel's HBM traffic drops to 192 B per
+// block, and a host caller ships 4x fewer bytes over PCIe.  Same structure as k_forward_fused_strip:
+// LDS-DMA of the wave's rows, lane-per-block compute, exact tier fed from LDS, tile write-out.
+// BS=1 needs W % 16 == 0 (a 16-byte DMA chunk holds the rows of two adjacent blocks).
+// ------------------------------------------------------------------------------------------------
+template <bool DC_EXACT, int BS, bool NT>
+__global__ __launch_bounds__(64) void k_forward_fused_u8(const unsigned char *__restrict__ in, size_t pitch, int wb,
+                                                         int nblk, QuantParams prm, int16_t *__restrict__ out,
+                                                         unsigned long long *counters)
+{
+    constexpr int ROWS = 8 * BS;                       // input rows of the wave's blocks
+    constexpr int ROW_BYTES = 64 * 8 * BS;             // bytes of one input row in LDS (64 blocks)
+    constexpr int IN_BYTES = ROWS * ROW_BYTES;         // 4 KiB (BS=1) / 16 KiB (BS=2)
+    constexpr int FRONT = IN_BYTES > TILE_BYTES ? IN_BYTES : TILE_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[FRONT + SCRATCH_DOUBLES * 8 + 128];
+    double *sA = reinterpret_cast<double *>(lds + FRONT);
+    double *sM = sA + 64;
+    int16_t *sP = reinterpret_cast<int16_t *>(lds + FRONT + SCRATCH_DOUBLES * 8);
+
+    const int lane = threadIdx.x;
+    const int g0 = blockIdx.x * 64;
+    const bool valid = g0 + lane < nblk;
+
+    if (BS == 1) {
+        // piece k = rows 2k, 2k+1; lane l -> row 2k + l/32, 16-byte chunk l%32 = blocks 2c, 2c+1
+        const int c = lane & 31;
+        const int gb = min(g0 + 2 * c, nblk - 2);           // even block index inside the plane (W/8 is even)
+        const int by = gb / wb, bx = gb - by * wb;
+        const unsigned char *src = in + ((size_t)by * 8 + (lane >> 5)) * pitch + (size_t)bx * 8;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + (size_t)(2 * k) * pitch),
+                                             (__attribute__((address_space(3))) void *)(lds + k * 1024), 16, 0, NT ? 2 : 0);
+    } else {
+        // one piece per input row: lane l <-> block l (16 bytes of the row)
+        const int gb = min(g0 + lane, nblk - 1);
+        const int by = gb / wb, bx = gb - by * wb;
+        const unsigned char *src = in + ((size_t)by * 16) * pitch + (size_t)bx * 16;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + (size_t)r * pitch),
+                                             (__attribute__((address_space(3))) void *)(lds + r * 1024), 16, 0, NT ? 2 : 0);
+    }
+    __syncthreads();
+
+    float v[64];
+    if (BS == 1) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const uint2 t = *reinterpret_cast<const uint2 *>(lds + r * 512 + lane * 8);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                v[r * 8 + c] = (float)((t.x >> (8 * c)) & 0xFFu);
+                v[r * 8 + 4 + c] = (float)((t.y >> (8 * c)) & 0xFFu);
+            }
+        }
+    } else {
+        // SubSampling.execute fused (pipeline/subsampling.py:9-11): integer 2x2 sums, then * 1/4 (exact)
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const u32x4 a = *reinterpret_cast<const u32x4 *>(lds + (2 * r) * 1024 + lane * 16);
+            const u32x4 b = *reinterpret_cast<const u32x4 *>(lds + (2 * r + 1) * 1024 + lane * 16);
+            const unsigned wa[4] = {a.x, a.y, a.z, a.w}, wb2[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const unsigned x = wa[c >> 1] >> (16 * (c & 1)), y = wb2[c >> 1] >> (16 * (c & 1));
+                const unsigned sum = (x & 0xFFu) + ((x >> 8) & 0xFFu) + (y & 0xFFu) + ((y >> 8) & 0xFFu);
+                v[r * 8 + c] = (float)sum * 0.25f;
+            }
+        }
+    }
+
+    jpegx_dct8x8_f32(v);
+    const float E = jpegx_fwd_err_bound(v[0]);            // pixel input: sum|x| == DC, exact
+    unsigned pk[32];
+    const float worst = quantise_zigzag_pack<true, DC_EXACT>(v, prm, E, pk);
+
+    unsigned long long flagged = __ballot(valid && !(worst < 0.5f));
+    census(counters, flagged, nblk - g0, lane);
+    if (prm.tune & 1) flagged = 0;
+    while (flagged) {   // exact tier, samples re-read from the rows still resident in LDS
+        const int b = __ffsll((long long)flagged) - 1;
+        flagged &= flagged - 1;
+        const int i = lane >> 3, j = lane & 7;
+        double a;
+        if (BS == 1) {
+            a = (double)lds[i * 512 + b * 8 + j];
+        } else {
+            const unsigned char *p0 = lds + (2 * i) * 1024 + b * 16 + 2 * j;
+            a = ((double)p0[0] + (double)p0[1] + (double)p0[1024] + (double)p0[1025]) / 4.0;   // np.mean
+        }
+        const double y = coop_fwd_exact(a, sA, sM, lane);
+        const double r = jpegx_quant_ref(y, lane, prm.mode, prm.param, c_rq64.v);
+        sP[c_zzinv.v[lane]] = (int16_t)jpegx_clamp_i16(r);
+        __syncthreads();
+        if (lane == b) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const u32x4 t = *reinterpret_cast<const u32x4 *>(reinterpret_cast<unsigned char *>(sP) + c * 16);
+                pk[c * 4 + 0] = t.x; pk[c * 4 + 1] = t.y; pk[c * 4 + 2] = t.z; pk[c * 4 + 3] = t.w;
+            }
+        }
+        __syncthreads();
+    }
+
+    __syncthreads();    // the input rows are dead: reuse the front of LDS as the swizzled output tile
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+        *reinterpret_cast<u32x4 *>(lds + tile_off(lane, c)) = u32x4{pk[c * 4 + 0], pk[c * 4 + 1], pk[c * 4 + 2], pk[c * 4 + 3]};
+    __syncthreads();
+    store_tile<NT>(lds, out, g0, nblk, lane);
+}
+
+// ------------------------------------------------------------------------------------------------
+// fused forward, ONE WAVEFRONT PER BLOCK (the layout sketched in BASELINE.json's north_star):
+// lane = one coefficient, the strip staged in LDS, both 1-D passes as 8 per-lane FMAs fed by
+// ds_bpermute (__shfl) from the 8 lanes of the row / column, quantise + zigzag scatter into the
+// LDS tile.  Kept as a selectable variant (JPEGX_F_TUNE_WAVE_PER_BLOCK) so that the choice of
+// the lane-per-block kernel above rests on a measurement (profiles/r01_ab_wave_per_block.txt),
+// not on an estimate: it needs 16 cross-lane fetches + 16 FMAs per BLOCK where lane-per-block
+// spends ~9 VALU instructions per block and no cross-lane traffic.  Results are identical.
+// The fp32 dots here are plain 8-term FMA chains (<= 9 roundings per pass), so the error
+// bound is scaled by 1.5 (24 u S) to stay rigorous.
+// ------------------------------------------------------------------------------------------------
+__device__ const float c_dct32[64] = {JPEGX_TABLE_DCT_MATRIX};   // fp32 roundings of C[k][n]
+
+constexpr int WPB_LDS_BYTES = STRIP_BYTES + TILE_BYTES + SCRATCH_DOUBLES * 8;
+
+template <int VAR, bool NT>
+__global__ __launch_bounds__(64) void k_forward_fused_wpb(const float *__restrict__ in, size_t pitch, int wb,
+                                                          int nblk, QuantParams prm, int16_t *__restrict__ out,
+                                                          unsigned long long *counters)
+{
+    constexpr bool PIXEL = (VAR & 1) != 0;
+    constexpr bool DC_EXACT = (VAR & 2) != 0;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[WPB_LDS_BYTES];
+    unsigned char *tile = lds + STRIP_BYTES;
+    double *sA = reinterpret_cast<double *>(lds + STRIP_BYTES + TILE_BYTES);
+    double *sM = sA + 64;
+
+    const int lane = threadIdx.x;
+    const int g0 = blockIdx.x * 64;
+    const int nvalid = min(64, nblk - g0);
+    {
+        const float *src[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int c = strip_swz(64 * j + lane);
+            const int gb = min(g0 + (c >> 1), nblk - 1);
+            const int by = gb / wb, bx = gb - by * wb;
+            src[j] = in + (size_t)by * 8 * pitch + (size_t)bx * 8 + (c & 1) * 4;
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src[0] + (size_t)r * pitch),
+                                             (__attribute__((address_space(3))) void *)(lds + r * 2048), 16, 0, NT ? 2 : 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src[1] + (size_t)r * pitch),
+                                             (__attribute__((address_space(3))) void *)(lds + r * 2048 + 1024), 16, 0, NT ? 2 : 0);
+        }
+    }
+    const int hi = lane >> 3, lo = lane & 7;
+    float crow[8], ccol[8];                     // C[l][0..7] for the row pass, C[k][0..7] for the column pass
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+        crow[n] = c_dct32[lo * 8 + n];
+        ccol[n] = c_dct32[hi * 8 + n];
+    }
+    float rq = 0.f;
+#pragma unroll
+    for (int n = 0; n < 64; ++n) rq = (lane == n) ? prm.rq32[n] : rq;   // kernarg SGPRs -> this lane's reciprocal
+    const int pz = c_zzinv.v[lane];
+    __syncthreads();                            // the strip has landed
+
+    unsigned nexact = 0;
+    for (int b = 0; b < nvalid; ++b) {
+        const int fb = ((b >> 2) ^ (b >> 3)) & 1;
+        const float x = *reinterpret_cast<const float *>(lds + hi * 2048 + ((2 * b + ((lo >> 2) ^ fb)) << 4) + (lo & 3) * 4);
+        float m = 0.f;                          // row pass: lane (i, l) = sum_n C[l][n] x[i][n]
+#pragma unroll
+        for (int n = 0; n < 8; ++n) m = fmaf(crow[n], __shfl(x, (lane & 56) | n), m);
+        float y = 0.f;                          // column pass: lane (k, l) = sum_i C[k][i] m[i][l]
+#pragma unroll
+        for (int i = 0; i < 8; ++i) y = fmaf(ccol[i], __shfl(m, (i << 3) | lo), y);
+        float S;
+        if (PIXEL) {
+            S = __shfl(y, 0);                   // DC = sum of the (non-negative) samples
+        } else {
+            S = fabsf(x);
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) S += __shfl_xor(S, d);
+        }
+        const float E = 1.5f * jpegx_fwd_err_bound(S);
+        const float t = y * rq;
+        float r = rintf(t);
+        bool unsafe = !(fmaf(E, fabsf(rq), fabsf(t - r)) < 0.5f);
+        if (DC_EXACT && lane == 0) unsafe = false;
+        bool any = __any(unsafe) != 0;
+        if (prm.tune & 1) any = false;
+        if (any) {                              // exact tier: already in the one-wave-per-block layout
+            const double yd = coop_fwd_exact((double)x, sA, sM, lane);
+            r = (float)jpegx_clamp_i16(jpegx_quant_ref(yd, lane, prm.mode, prm.param, c_rq64.v));
+            ++nexact;
+        }
+        const int q = PIXEL ? (int)r : min(max((int)r, -32768), 32767);
+        *reinterpret_cast<int16_t *>(tile + tile_off(b, pz >> 3) + (pz & 7) * 2) = (int16_t)q;
+    }
+    if (counters != nullptr && lane == 0) {
+        atomicAdd(&counters[0], (unsigned long long)nexact);
+        atomicAdd(&counters[1], (unsigned long long)nvalid);
+    }
+    __syncthreads();
+    unsigned char *dst = reinterpret_cast<unsigned char *>(out) + (size_t)g0 * 128;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int row = i * 8 + (lane >> 3), c = lane & 7;
+        const u32x4 q4 = *reinterpret_cast<const u32x4 *>(tile + tile_off(row, c));
+        if (row < nvalid) st_u32x4<NT>(dst + (size_t)row * 128 + c * 16, q4);
+    }
+}
+
+template <int BS, bool NT, int STAGED = 0>
+int launch_forward(const float *d_in, int H, int W, ptrdiff_t pitch, const QuantParams &qp, unsigned flags,
+                   int16_t *d_out, hipStream_t st)
+{
+    const int wb = W / 8, nblk = (H / 8) * wb;
+    const dim3 grid((nblk + 63) / 64), block(64);
+    const bool pixel = (flags & JPEGX_F_PIXEL_INPUT) != 0;
+    // DC is an exact integer multiple of 2^-8 and rq[0] a power of two -> DC/q needs no tie check
+    const bool dc_exact = pixel && is_pow2_float(qp.rq32[0]) &&
+                          (qp.mode != JPEGX_Q_DIVIDE || (double)qp.rq32[0] * qp.param == 1.0);
+    if (BS == 1 && (flags & JPEGX_F_TUNE_WAVE_PER_BLOCK)) {
+        if (dc_exact)
+            hipLaunchKernelGGL((k_forward_fused_wpb<3, NT>), grid, block, 0, st, d_in, (size_t)pitch, wb, nblk, qp, d_out, g_counters);
+        else if (pixel)
+            hipLaunchKernelGGL((k_forward_fused_wpb<1, NT>), grid, block, 0, st, d_in, (size_t)pitch, wb, nblk, qp, d_out, g_counters);
+        else
+            hipLaunchKernelGGL((k_forward_fused_wpb<0, NT>), grid, block, 0, st, d_in, (size_t)pitch, wb, nblk, qp, d_out, g_counters);
+    } else if (BS == 1 && !(flags & JPEGX_F_TUNE_NO_STRIP)) {
+        if (dc_exact)
+            hipLaunchKernelGGL((k_forward_fused_strip<3, NT>), grid, block, 0, st, d_in, (size_t)pitch, wb, nblk, qp, d_out, g_counters);
+        else if (pixel)
+            hipLaunchKernelGGL((k_forward_fused_strip<1, NT>), grid, block, 0, st, d_in, (size_t)pitch, wb, nblk, qp, d_out, g_counters);
+        else
+            hipLaunchKernelGGL((k_forward_fused_strip<0, NT>), grid, block, 0, st, d_in, (size_t)pitch, wb, nblk, qp, d_out, g_counters);
+    } else if (dc_exact)
+        hipLaunchKernelGGL((k_forward_fused<3, BS, NT, STAGED>), grid, block, 0, st, d_in, (size_t)pitch, wb, nblk, qp, d_out, g_counters);
+    else if (pixel)
+        hipLaunchKernelGGL((k_forward_fused<1, BS, NT, STAGED>), grid, block, 0, st, d_in, (size_t)pitch, wb, nblk, qp, d_out, g_counters);
+    else
+        hipLaunchKernelGGL((k_forward_fused<0, BS, NT, STAGED>), grid, block, 0, st, d_in, (size_t)pitch, wb, nblk, qp, d_out, g_counters);
+    HIP_TRY(hipGetLastError());
+    return JPEGX_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int jpegx_forward_fused_pooled(const float *d_in, int H, int W, ptrdiff_t pitch, int bs, int mode, double param,
+                               unsigned flags, int16_t *d_out, jpegx_stream_t stream)
+{
+    if (bs != 1 && bs != 2 && bs != 4) return fail(JPEGX_E_UNSUPPORTED, "fused mean-pool supports block_size 1, 2 and 4");
+    int rc = check_plane(d_in, d_out, H, W, pitch / bs, 1);
+    if (rc) return rc;
+    if (pitch < (ptrdiff_t)W * bs || (pitch % 4) != 0 || !aligned16(d_in) || !aligned16(d_out))
+        return fail(JPEGX_E_INVALID, "forward: pitch must be a multiple of 4 floats and >= W*bs; pointers 16-byte aligned");
+    QuantParams qp;
+    rc = fill_forward_params(mode, param, &qp);
+    if (rc) return rc;
+    if (flags & JPEGX_F_TUNE_SKIP_EXACT) qp.tune |= 1;
+    hipStream_t st = (hipStream_t)stream;
+    // Pooled input: staged through LDS by default (whole-line nontemporal DMA).  The per-lane
+    // variant reads partial lines per instruction (16 B at a 32*bs-byte lane stride); nontemporal
+    // loads then refetch every line and lose 30-60 % (profiles/r01_ab_pooled.txt), so that variant
+    // always uses the default cache policy.
+    if (bs > 1 && !(flags & JPEGX_F_TUNE_NO_STRIP)) {
+        const bool nt = !(flags & JPEGX_F_TUNE_NO_NT);
+        const int rpp = (flags & JPEGX_F_TUNE_POOL_ROWS_LO) ? 1 : ((flags & JPEGX_F_TUNE_POOL_ROWS_HI) ? 4 : 2);   // experiment: rows per phase
+#define JPEGX_LF(BSV, RPPV) (nt ? launch_forward<BSV, true, RPPV>(d_in, H, W, pitch, qp, flags, d_out, st) \
+                                : launch_forward<BSV, false, RPPV>(d_in, H, W, pitch, qp, flags, d_out, st))
+        if (bs == 2) return rpp == 1 ? JPEGX_LF(2, 1) : (rpp == 4 ? JPEGX_LF(2, 4) : JPEGX_LF(2, 2));
+        return rpp == 4 ? JPEGX_LF(4, 2) : JPEGX_LF(4, 1);
+#undef JPEGX_LF
+    }
+    if (bs == 2) return launch_forward<2, false>(d_in, H, W, pitch, qp, flags, d_out, st);
+    if (bs == 4) return launch_forward<4, false>(d_in, H, W, pitch, qp, flags, d_out, st);
+    if (flags & JPEGX_F_TUNE_NO_NT) return launch_forward<1, false>(d_in, H, W, pitch, qp, flags, d_out, st);
+    return launch_forward<1, true>(d_in, H, W, pitch, qp, flags, d_out, st);
+}
+
+int jpegx_forward_fused(const float *d_in, int H, int W, ptrdiff_t pitch, int mode, double param, unsigned flags,
+                        int16_t *d_out, jpegx_stream_t stream)
+{
+    return jpegx_forward_fused_pooled(d_in, H, W, pitch, 1, mode, param, flags, d_out, stream);
+}
+
+int jpegx_forward_fused_u8(const uint8_t *d_in, int H, int W, ptrdiff_t pitch, int bs, int mode, double param,
+                           unsigned flags, int16_t *d_out, jpegx_stream_t stream)
+{
+    if (bs != 1 && bs != 2) return fail(JPEGX_E_UNSUPPORTED, "uint8 forward supports block_size 1 and 2");
+    int rc = check_plane(d_in, d_out, H, W, pitch / bs, 1);
+    if (rc) return rc;
+    if (pitch < (ptrdiff_t)W * bs || (pitch % 16) != 0 || !aligned16(d_in) || !aligned16(d_out))
+        return fail(JPEGX_E_INVALID, "forward_u8: pitch must be a multiple of 16 bytes and >= W*bs; pointers 16-byte aligned");
+    if (bs == 1 && (W % 16) != 0) return fail(JPEGX_E_UNSUPPORTED, "forward_u8 with block_size 1 needs W to be a multiple of 16");
+    QuantParams qp;
+    rc = fill_forward_params(mode, param, &qp);
+    if (rc) return rc;
+    if (flags & JPEGX_F_TUNE_SKIP_EXACT) qp.tune |= 1;
+    const int wb = W / 8, nblk = (H / 8) * wb;
+    const dim3 grid((nblk + 63) / 64), block(64);
+    hipStream_t st = (hipStream_t)stream;
+    const bool dc_exact = is_pow2_float(qp.rq32[0]) && (qp.mode != JPEGX_Q_DIVIDE || (double)qp.rq32[0] * qp.param == 1.0);
+    const bool nt = !(flags & JPEGX_F_TUNE_NO_NT);
+#define JPEGX_LU8(DC, BSV) \
+    do { if (nt) hipLaunchKernelGGL((k_forward_fused_u8<DC, BSV, true>), grid, block, 0, st, d_in, (size_t)pitch, wb, nblk, qp, d_out, g_counters); \
+         else hipLaunchKernelGGL((k_forward_fused_u8<DC, BSV, false>), grid, block, 0, st, d_in, (size_t)pitch, wb, nblk, qp, d_out, g_counters); } while (0)
+    if (bs == 1) { if (dc_exact) JPEGX_LU8(true, 1); else JPEGX_LU8(false, 1); }
+    else { if (dc_exact) JPEGX_LU8(true, 2); else JPEGX_LU8(false, 2); }
+#undef JPEGX_LU8
+    HIP_TRY(hipGetLastError());
+    return JPEGX_OK;
+}
+int jpegx_host_forward_fused(const float *h_in, int H, int W, ptrdiff_t pitch, int mode, double param, unsigned flags,
+                             int16_t *h_out)
+{
+    if (H <= 0 || W <= 0 || pitch < W) return fail(JPEGX_E_INVALID, "bad plane shape");
+    return host_roundtrip(h_in, (size_t)H * pitch * 4, h_out, (size_t)H * W * 2, [&](void *di, void *dout, jpegx_stream_t s) {
+        return jpegx_forward_fused((const float *)di, H, W, pitch, mode, param, flags, (int16_t *)dout, s);
+    });
+}
+}  // extern "C"

@@ -1,0 +1,136 @@
+// jpegx_internal.h -- host-side helpers shared by the translation units of libjpegx.so: the
+// thread-local error string, argument validation, quantiser parameter tables, RAII for the
+// synchronous host-pointer conveniences.  Not part of the public ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/jpegx.h"
+#include "jpegx_device.h"
+
+namespace jpegx_detail {
+extern thread_local char g_err[512];                    // jpegx_runtime.hip
+extern thread_local unsigned long long *g_counters;     // jpegx_set_debug_counters
+}  // namespace jpegx_detail
+
+namespace {
+using jpegx_detail::g_counters;
+using jpegx_detail::g_err;
+
+int fail(int code, const char *fmt, const char *detail = "")
+{
+    snprintf(g_err, sizeof(g_err), fmt, detail);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                    \
+    do {                                                                                 \
+        hipError_t e_ = (expr);                                                          \
+        if (e_ != hipSuccess) {                                                          \
+            snprintf(g_err, sizeof(g_err), "%s failed: %s", #expr, hipGetErrorString(e_)); \
+            return JPEGX_E_HIP;                                                          \
+        }                                                                                \
+    } while (0)
+
+int check_plane(const void *in, const void *out, int H, int W, ptrdiff_t pitch, int align_elems)
+{
+    if (in == nullptr || out == nullptr) return fail(JPEGX_E_INVALID, "null device pointer");
+    if (H <= 0 || W <= 0 || (H % 8) != 0 || (W % 8) != 0)
+        return fail(JPEGX_E_INVALID, "plane height and width must be positive multiples of 8");
+    if (pitch < W) return fail(JPEGX_E_INVALID, "pitch smaller than width");
+    if (align_elems > 1 && (pitch % align_elems) != 0)
+        return fail(JPEGX_E_INVALID, "pitch must keep rows 16-byte aligned");
+    if ((long long)(H / 8) * (long long)(W / 8) > 0x7FFFFFC0LL)
+        return fail(JPEGX_E_INVALID, "more than 2^31 blocks in one launch");
+    return JPEGX_OK;
+}
+
+int aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+int is_pow2_float(float f)
+{
+    int e;
+    return f > 0.f && frexpf(f, &e) == 0.5f;
+}
+
+// forward table: fp32 reciprocals (fast tier only; the exact tier uses float64 1.0/q or a true division)
+int fill_forward_params(int mode, double param, QuantParams *qp)
+{
+    qp->mode = mode;
+    qp->param = param;
+    qp->tune = 0;
+    switch (mode) {
+    case JPEGX_Q_NONE:
+        for (int n = 0; n < 64; ++n) qp->rq32[n] = 1.0f;
+        return JPEGX_OK;
+    case JPEGX_Q_DISCARD: {
+        if (!(param >= 0.0) || param != (double)(int)param) return fail(JPEGX_E_INVALID, "discard: keep must be a non-negative integer");
+        const int keep = (int)param;
+        for (int n = 0; n < 64; ++n) qp->rq32[n] = ((n >> 3) < keep && (n & 7) < keep) ? 1.0f : 0.0f;
+        return JPEGX_OK;
+    }
+    case JPEGX_Q_DIVIDE:
+        if (!(param != 0.0) || !(fabs(param) <= 1e30)) return fail(JPEGX_E_INVALID, "divide: divisor must be finite and non-zero");
+        for (int n = 0; n < 64; ++n) qp->rq32[n] = (float)(1.0 / param);
+        return JPEGX_OK;
+    case JPEGX_Q_QTABLE:
+        for (int n = 0; n < 64; ++n) qp->rq32[n] = (float)(1.0 / (double)kQT.v[n]);
+        return JPEGX_OK;
+    default:
+        return fail(JPEGX_E_INVALID, "unknown quantiser mode");
+    }
+}
+
+// inverse table: fp32 multipliers of Quantizer.restore
+int fill_inverse_params(int mode, double param, QuantParams *qp)
+{
+    qp->mode = mode;
+    qp->param = param;
+    qp->tune = 0;
+    switch (mode) {
+    case JPEGX_Q_NONE:
+    case JPEGX_Q_DISCARD:
+        for (int n = 0; n < 64; ++n) qp->rq32[n] = 1.0f;
+        return JPEGX_OK;
+    case JPEGX_Q_DIVIDE:
+        if (!(fabs(param) <= 1e30)) return fail(JPEGX_E_INVALID, "divide: divisor must be finite");
+        for (int n = 0; n < 64; ++n) qp->rq32[n] = (float)param;
+        return JPEGX_OK;
+    case JPEGX_Q_QTABLE:
+        for (int n = 0; n < 64; ++n) qp->rq32[n] = (float)kQT.v[n];
+        return JPEGX_OK;
+    default:
+        return fail(JPEGX_E_INVALID, "unknown quantiser mode");
+    }
+}
+
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t bytes) { HIP_TRY(hipMalloc(&p, bytes ? bytes : 1)); return JPEGX_OK; }
+};
+struct Stream {
+    hipStream_t s = nullptr;
+    ~Stream() { if (s) (void)hipStreamDestroy(s); }
+    int create() { HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking)); return JPEGX_OK; }
+};
+
+// generic "copy in, run, copy out" helper
+template <typename F>
+int host_roundtrip(const void *h_in, size_t in_bytes, void *h_out, size_t out_bytes, F &&run)
+{
+    if (!h_in || !h_out) return fail(JPEGX_E_INVALID, "null host pointer");
+    DevBuf din, dout;
+    Stream st;
+    int rc;
+    if ((rc = din.alloc(in_bytes)) || (rc = dout.alloc(out_bytes)) || (rc = st.create())) return rc;
+    HIP_TRY(hipMemcpyAsync(din.p, h_in, in_bytes, hipMemcpyHostToDevice, st.s));
+    if ((rc = run(din.p, dout.p, (jpegx_stream_t)st.s))) return rc;
+    HIP_TRY(hipMemcpyAsync(h_out, dout.p, out_bytes, hipMemcpyDeviceToHost, st.s));
+    HIP_TRY(hipStreamSynchronize(st.s));
+    return JPEGX_OK;
+}
+
+}  // namespace

@@ -1,4 +1,4 @@
-// jpegx_math.h -- per-block arithmetic shared by every kernel in jpegx_kernels.hip.
+// jpegx_math.h -- per-block arithmetic shared by every kernel of libjpegx.so (jpegx_forward / _inverse / _stage .hip).
 //
 // Everything here is a plain inline function on registers so that tests/emul can compile
 // the very same arithmetic for the host (g++ -mfma -ffp-contract=off) and check it against

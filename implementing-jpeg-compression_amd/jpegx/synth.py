@@ -1,7 +1,7 @@
 """Integer-only synthetic plane generators.
 
 The same arithmetic is implemented on the device by ``jpegx_generate_plane``
-(csrc/jpegx_kernels.hip) so that host and GPU produce identical bits without any
+(csrc/jpegx_stage.hip) so that host and GPU produce identical bits without any
 host->device copy.  Values are integers in 0..255 ("noise") or 0..206
 ("smooth"), exactly representable in fp32.
 

@@ -36,7 +36,7 @@ def _ensure_built():
         return
     hipcc = shutil.which("hipcc") or ("/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else None)
     if hipcc is not None:
-        subprocess.check_call(["make", "-s", "-C", os.path.join(PKG, "csrc"), "HIPCC=" + hipcc])
+        subprocess.check_call(["make", "-s", "-j4", "-C", os.path.join(PKG, "csrc"), "HIPCC=" + hipcc])
     if shutil.which("gcc") is not None:
         subprocess.check_call(["make", "-s", "-C", os.path.join(REPO, "oracle")])
 
