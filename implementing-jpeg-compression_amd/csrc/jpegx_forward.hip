@@ -310,6 +310,93 @@ __global__ __launch_bounds__(64) void k_forward_fused_strip(const float *__restr
 }
 
 // ------------------------------------------------------------------------------------------------
+// fused forward, ALL-FLOAT64 variant.  With quantisers whose step is close to 1 (mode 'none', small
+// divisors, wide 'discard' windows) the rounding margin E/q of the fp32 tier is so wide that most
+// blocks would fall back to the cooperative exact tier (80 % of noise blocks for 'none': 5 Gblocks/s).
+// For those the whole block is computed per lane in float64 in the reference's operation order
+// straight away -- 1408 fp64 flops per block, no flags, no second tier -- which is bit-exact by
+// construction.  Same LDS-DMA strip staging and tile write-out as the default kernel.  Chosen by
+// the launcher from the expected exact-tier share (jpegx_forward_fused_pooled).
+// ------------------------------------------------------------------------------------------------
+template <bool NT>
+__global__ __launch_bounds__(64) void k_forward_fused_strip_f64(const float *__restrict__ in, size_t pitch, int wb,
+                                                                int nblk, QuantParams prm, int16_t *__restrict__ out,
+                                                                unsigned long long *counters)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char lds[STRIP_BYTES];
+    const int lane = threadIdx.x;
+    const int g0 = blockIdx.x * 64;
+    {
+        const float *src[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int c = strip_swz(64 * j + lane);
+            const int gb = min(g0 + (c >> 1), nblk - 1);
+            const int by = gb / wb, bx = gb - by * wb;
+            src[j] = in + (size_t)by * 8 * pitch + (size_t)bx * 8 + (c & 1) * 4;
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src[0] + (size_t)r * pitch),
+                                             (__attribute__((address_space(3))) void *)(lds + r * 2048), 16, 0, NT ? 2 : 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src[1] + (size_t)r * pitch),
+                                             (__attribute__((address_space(3))) void *)(lds + r * 2048 + 1024), 16, 0, NT ? 2 : 0);
+        }
+    }
+    __syncthreads();
+
+    // The block stays in registers as fp32 (64 VGPRs); for each output column l the row pass
+    // M[i][l] = C[l] . A[i] (rows first, transforms.py:46-58) is evaluated for the 8 rows, then the
+    // column pass Y[k][l] = C[k] . M[:, l], quantised on the fly (quantizers.py:4-49) and packed at
+    // its zigzag position.  Keeping only one column of M live (16 VGPRs instead of 128) costs 7 extra
+    // float->double conversions per sample but lifts occupancy from 1 to 3 waves per SIMD.
+    float a[64];
+    const int f = ((lane >> 2) ^ (lane >> 3)) & 1;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const f32x4 lo = *reinterpret_cast<const f32x4 *>(lds + i * 2048 + ((2 * lane + f) << 4));
+        const f32x4 hi = *reinterpret_cast<const f32x4 *>(lds + i * 2048 + ((2 * lane + (f ^ 1)) << 4));
+        a[i * 8 + 0] = lo.x; a[i * 8 + 1] = lo.y; a[i * 8 + 2] = lo.z; a[i * 8 + 3] = lo.w;
+        a[i * 8 + 4] = hi.x; a[i * 8 + 5] = hi.y; a[i * 8 + 6] = hi.z; a[i * 8 + 7] = hi.w;
+    }
+    unsigned pk[32];
+#pragma unroll
+    for (int w = 0; w < 32; ++w) pk[w] = 0u;
+#pragma unroll
+    for (int l = 0; l < 8; ++l) {
+        double m[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            // opaque to the optimiser: otherwise the 64 conversions are hoisted out of the column loop
+            // and all 64 doubles stay live (256 VGPRs, 1 wave per SIMD)
+            asm volatile("" : "+v"(a[i * 8 + 0]), "+v"(a[i * 8 + 1]), "+v"(a[i * 8 + 2]), "+v"(a[i * 8 + 3]),
+                              "+v"(a[i * 8 + 4]), "+v"(a[i * 8 + 5]), "+v"(a[i * 8 + 6]), "+v"(a[i * 8 + 7]));
+            const double x[8] = {(double)a[i * 8 + 0], (double)a[i * 8 + 1], (double)a[i * 8 + 2], (double)a[i * 8 + 3],
+                                 (double)a[i * 8 + 4], (double)a[i * 8 + 5], (double)a[i * 8 + 6], (double)a[i * 8 + 7]};
+            m[i] = jpegx_dot8_ref(&c_dct[l * 8], x, 1);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int n = k * 8 + l;
+            const double y = jpegx_dot8_ref(&c_dct[k * 8], m, 1);
+            const int q = jpegx_clamp_i16(jpegx_quant_ref(y, n, prm.mode, prm.param, c_rq64.v));
+            constexpr I64 zi = make_zzinv();
+            const int p = zi.v[n];
+            pk[p >> 1] |= ((unsigned)q & 0xFFFFu) << (16 * (p & 1));
+        }
+        asm volatile("" : "+v"(pk[0]) : : "memory");   // keep the columns in program order (register pressure)
+    }
+    census(counters, 0ull, nblk - g0, lane);
+
+    __syncthreads();    // the strip is dead: reuse its first 8 KiB as the swizzled output tile
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+        *reinterpret_cast<u32x4 *>(lds + tile_off(lane, c)) = u32x4{pk[c * 4 + 0], pk[c * 4 + 1], pk[c * 4 + 2], pk[c * 4 + 3]};
+    __syncthreads();
+    store_tile<NT>(lds, out, g0, nblk, lane);
+}
+
+// ------------------------------------------------------------------------------------------------
 // fused forward on uint8 planes (the form in which image bands actually arrive: util.band_to_array,
 // util.py:110-112).  64 B (BS=1) or 256 B (BS=2, SubSampling 2x2 mean fused) are read per block
 // instead of 256 B / 1 KiB of fp32, which matters twice: the kernel's HBM traffic drops to 192 B per
@@ -532,6 +619,20 @@ __global__ __launch_bounds__(64) void k_forward_fused_wpb(const float *__restric
     }
 }
 
+// Expected share of blocks that the fp32 tier would hand to the exact tier, for typical 8-bit content
+// (sum|x| ~ 64 * 128): a coefficient is flagged with probability ~ 2 E / q.  Only steers the choice
+// between two kernels that produce identical output.
+double expected_exact_share(const QuantParams &qp)
+{
+    const double E = 8192.0 * 0x1p-20;
+    double keep = 1.0;
+    for (int n = 0; n < 64; ++n) {
+        const double pflag = 2.0 * E * fabs((double)qp.rq32[n]);
+        keep *= pflag < 1.0 ? 1.0 - pflag : 0.0;
+    }
+    return 1.0 - keep;
+}
+
 template <int BS, bool NT, int STAGED = 0>
 int launch_forward(const float *d_in, int H, int W, ptrdiff_t pitch, const QuantParams &qp, unsigned flags,
                    int16_t *d_out, hipStream_t st)
@@ -542,7 +643,10 @@ int launch_forward(const float *d_in, int H, int W, ptrdiff_t pitch, const Quant
     // DC is an exact integer multiple of 2^-8 and rq[0] a power of two -> DC/q needs no tie check
     const bool dc_exact = pixel && is_pow2_float(qp.rq32[0]) &&
                           (qp.mode != JPEGX_Q_DIVIDE || (double)qp.rq32[0] * qp.param == 1.0);
-    if (BS == 1 && (flags & JPEGX_F_TUNE_WAVE_PER_BLOCK)) {
+    if (BS == 1 && !(flags & (JPEGX_F_TUNE_WAVE_PER_BLOCK | JPEGX_F_TUNE_NO_STRIP | JPEGX_F_TUNE_NO_F64_KERNEL)) &&
+        ((flags & JPEGX_F_TUNE_F64_KERNEL) || expected_exact_share(qp) > 0.35)) {
+        hipLaunchKernelGGL((k_forward_fused_strip_f64<NT>), grid, block, 0, st, d_in, (size_t)pitch, wb, nblk, qp, d_out, g_counters);
+    } else if (BS == 1 && (flags & JPEGX_F_TUNE_WAVE_PER_BLOCK)) {
         if (dc_exact)
             hipLaunchKernelGGL((k_forward_fused_wpb<3, NT>), grid, block, 0, st, d_in, (size_t)pitch, wb, nblk, qp, d_out, g_counters);
         else if (pixel)

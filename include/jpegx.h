@@ -59,6 +59,8 @@ typedef enum jpegx_quant_mode {
 #define JPEGX_F_TUNE_SKIP_EXACT 0x400u /* TIMING ONLY: skip the float64 exact tier (output no longer bit-exact) */
 #define JPEGX_F_TUNE_WAVE_PER_BLOCK 0x800u /* forward: one-wavefront-per-block kernel (lane = coefficient,   \
                                               ds_bpermute 1-D passes) instead of lane-per-block; same output */
+#define JPEGX_F_TUNE_F64_KERNEL 0x4000u    /* forward: force the all-float64 lane-per-block kernel           */
+#define JPEGX_F_TUNE_NO_F64_KERNEL 0x8000u /* forward: never pick it (fp32 tier + exact tier always)          */
 #define JPEGX_F_TUNE_POOL_ROWS_LO 0x1000u /* pooled forward: fewer input rows per LDS phase (experiment) */
 #define JPEGX_F_TUNE_POOL_ROWS_HI 0x2000u /* pooled forward: more input rows per LDS phase (experiment)  */
 #define JPEGX_F_TUNE_NO_STRIP 0x200u /* forward: per-lane global loads instead of LDS-DMA staging    */

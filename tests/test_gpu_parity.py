@@ -166,7 +166,7 @@ def test_bad_arguments_raise(gpu):
         gpu.forward_fused(np.zeros((8, 8), np.float32), "bogus")
 
 
-@pytest.mark.parametrize("flags", [0x100, 0x200, 0x300, 0x800, 0x900])
+@pytest.mark.parametrize("flags", [0x100, 0x200, 0x300, 0x800, 0x900, 0x4000, 0x8000])
 @pytest.mark.parametrize("kind", ["noise", "smooth"])
 def test_forward_tuning_variants_are_bit_identical(gpu, kind, flags):
     """Cache-policy and LDS-strip variants of the fused forward kernel give the same integers."""
