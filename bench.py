@@ -294,7 +294,7 @@ def main():
         traffic = None
     achieved = BYTES_PER_BLOCK * blocks_per_step / (kernel_ms * 1e-3) / 1e9
     result = {
-        "metric": "M 8x8 blocks/sec (DCT+quant+zigzag fused forward)",
+        "metric": "M 8x8 blocks/sec (DCT+quant+zigzag)",
         "value": round(value, 2), "unit": "Mblocks/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(t_max / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
