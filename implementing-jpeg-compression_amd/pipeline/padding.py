@@ -7,8 +7,11 @@ class Padding(AlgorithmStep):
     step_index = 0
 
     def execute(self, array):
-        # the reference hands the input object back untouched when block_size is 1 (padding.py:9-10)
-        return array if self._config.block_size == 1 else pad_array(array, self._config.block_size)
+        bs = self._config.block_size
+        if bs == 1:
+            return array          # the very same object, as in the reference (padding.py:9-10)
+        return pad_array(array, bs)
 
     def invert(self, array):
-        return undo_pad_array(array, self.calculate_padding(self._config.block_size))
+        extra_rows, extra_cols = self.calculate_padding(self._config.block_size)
+        return undo_pad_array(array, (extra_rows, extra_cols))
