@@ -65,15 +65,16 @@ class DivisionQuantizer(RoundingQuantizer):
         return a * self.divisor
 
 
+# the JPEG Annex-K luminance table (reference: quantizers.py:35-42), kept flat here
+_LUMINANCE = (16, 11, 10, 16, 24, 40, 51, 61, 12, 12, 14, 19, 26, 58, 60, 55,
+              14, 13, 16, 24, 40, 57, 69, 56, 14, 17, 22, 29, 51, 87, 80, 62,
+              18, 22, 37, 56, 68, 109, 103, 77, 24, 35, 55, 64, 81, 104, 113, 92,
+              49, 64, 78, 87, 103, 121, 120, 101, 72, 92, 95, 98, 112, 100, 103, 99)
+
+
 class JpegQuantizationTable(RoundingQuantizer):
     """Standard luminance table: round(a * (1.0 / q)), restore round(a * q) (quantizers.py:34-53)."""
-    # the JPEG Annex-K luminance table (quantizers.py:35-42), kept flat here and exposed as the
-    # nested list the reference's callers expect
-    _LUMINANCE = (16, 11, 10, 16, 24, 40, 51, 61, 12, 12, 14, 19, 26, 58, 60, 55,
-                  14, 13, 16, 24, 40, 57, 69, 56, 14, 17, 22, 29, 51, 87, 80, 62,
-                  18, 22, 37, 56, 68, 109, 103, 77, 24, 35, 55, 64, 81, 104, 113, 92,
-                  49, 64, 78, 87, 103, 121, 120, 101, 72, 92, 95, 98, 112, 100, 103, 99)
-    table = [list(_LUMINANCE[r * 8:(r + 1) * 8]) for r in range(8)]
+    table = [list(_LUMINANCE[r * 8:(r + 1) * 8]) for r in range(8)]  # nested list, as callers expect
 
     def __init__(self):
         self._qtable = np.array(self.table)
