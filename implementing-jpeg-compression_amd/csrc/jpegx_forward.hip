@@ -411,7 +411,9 @@ __global__ __launch_bounds__(64) void k_forward_fused_u8(const unsigned char *__
 {
     constexpr int ROWS = 8 * BS;                       // input rows of the wave's blocks
     constexpr int ROW_BYTES = 64 * 8 * BS;             // bytes of one input row in LDS (64 blocks)
-    constexpr int IN_BYTES = ROWS * ROW_BYTES;         // 4 KiB (BS=1) / 16 KiB (BS=2)
+    // 4 KiB (BS=1) / 16 KiB (BS=2) hold all rows at once; BS=4 (64 KiB) is streamed in 4 phases of
+    // 8 input rows = 16 KiB, laid out exactly like the fp32 strip (2 KiB rows, strip_swz chunks)
+    constexpr int IN_BYTES = (BS == 4) ? STRIP_BYTES : ROWS * ROW_BYTES;
     constexpr int FRONT = IN_BYTES > TILE_BYTES ? IN_BYTES : TILE_BYTES;
     __shared__ __attribute__((aligned(16))) unsigned char lds[FRONT + SCRATCH_DOUBLES * 8 + 128];
     double *sA = reinterpret_cast<double *>(lds + FRONT);
@@ -422,7 +424,54 @@ __global__ __launch_bounds__(64) void k_forward_fused_u8(const unsigned char *__
     const int g0 = blockIdx.x * 64;
     const bool valid = g0 + lane < nblk;
 
-    if (BS == 1) {
+    float v[64];
+    if (BS == 4) {
+        // SubSampling.execute fused for block_size 4 (the CLI default, compress.py:33): per phase the
+        // wave brings in 8 input rows of 2 KiB (lane l of piece j <-> chunk strip_swz(64 j + l) = half
+        // (c & 1) of block c >> 1), every lane sums its 4 x 4 byte tiles with integer adds.
+        const unsigned char *src[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int c = strip_swz(64 * j + lane);
+            const int gb = min(g0 + (c >> 1), nblk - 1);
+            const int by = gb / wb, bx = gb - by * wb;
+            src[j] = in + ((size_t)by * 32) * pitch + (size_t)bx * 32 + (c & 1) * 16;
+        }
+        const int f = ((lane >> 2) ^ (lane >> 3)) & 1;
+#pragma unroll
+        for (int ph = 0; ph < 4; ++ph) {
+            __syncthreads();                            // previous phase's LDS reads are done
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const size_t roff = (size_t)(ph * 8 + r) * pitch;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src[0] + roff),
+                                                 (__attribute__((address_space(3))) void *)(lds + r * 2048), 16, 0, NT ? 2 : 0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src[1] + roff),
+                                                 (__attribute__((address_space(3))) void *)(lds + r * 2048 + 1024), 16, 0, NT ? 2 : 0);
+            }
+            __syncthreads();                            // the phase has landed
+#pragma unroll
+            for (int ro = 0; ro < 2; ++ro) {            // two output rows per phase
+                unsigned sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    const int r = ro * 4 + a;
+                    const u32x4 lo = *reinterpret_cast<const u32x4 *>(lds + r * 2048 + ((2 * lane + f) << 4));
+                    const u32x4 hi = *reinterpret_cast<const u32x4 *>(lds + r * 2048 + ((2 * lane + (f ^ 1)) << 4));
+                    const unsigned w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+                    for (int c = 0; c < 8; ++c)
+                        sum[c] += (w[c] & 0xFFu) + ((w[c] >> 8) & 0xFFu) + ((w[c] >> 16) & 0xFFu) + (w[c] >> 24);
+                }
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    v[(ph * 2 + ro) * 8 + c] = (float)sum[c] * 0.0625f;
+                    asm volatile("" : "+v"(v[(ph * 2 + ro) * 8 + c]) : : "memory");   // fold now (register pressure)
+                }
+            }
+        }
+        __syncthreads();
+    } else if (BS == 1) {
         // piece k = rows 2k, 2k+1; lane l -> row 2k + l/32, 16-byte chunk l%32 = blocks 2c, 2c+1
         const int c = lane & 31;
         const int gb = min(g0 + 2 * c, nblk - 2);           // even block index inside the plane (W/8 is even)
@@ -444,8 +493,9 @@ __global__ __launch_bounds__(64) void k_forward_fused_u8(const unsigned char *__
     }
     __syncthreads();
 
-    float v[64];
-    if (BS == 1) {
+    if (BS == 4) {
+        // already pooled above
+    } else if (BS == 1) {
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             const uint2 t = *reinterpret_cast<const uint2 *>(lds + r * 512 + lane * 8);
@@ -486,9 +536,21 @@ __global__ __launch_bounds__(64) void k_forward_fused_u8(const unsigned char *__
         double a;
         if (BS == 1) {
             a = (double)lds[i * 512 + b * 8 + j];
-        } else {
+        } else if (BS == 2) {
             const unsigned char *p0 = lds + (2 * i) * 1024 + b * 16 + 2 * j;
             a = ((double)p0[0] + (double)p0[1] + (double)p0[1024] + (double)p0[1025]) / 4.0;   // np.mean
+        } else {
+            // block_size 4: the rows are no longer in LDS, re-read the 4 x 4 tile from global memory
+            const int gb = g0 + b;
+            const int byb = gb / wb, bxb = gb - byb * wb;
+            const unsigned char *p0 = in + ((size_t)byb * 32 + 4 * i) * pitch + (size_t)bxb * 32 + 4 * j;
+            unsigned tot = 0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const unsigned w = *reinterpret_cast<const unsigned *>(p0 + (size_t)u * pitch);
+                tot += (w & 0xFFu) + ((w >> 8) & 0xFFu) + ((w >> 16) & 0xFFu) + (w >> 24);
+            }
+            a = (double)tot / 16.0;                                                             // np.mean
         }
         const double y = coop_fwd_exact(a, sA, sM, lane);
         const double r = jpegx_quant_ref(y, lane, prm.mode, prm.param, c_rq64.v);
@@ -714,7 +776,7 @@ int jpegx_forward_fused(const float *d_in, int H, int W, ptrdiff_t pitch, int mo
 int jpegx_forward_fused_u8(const uint8_t *d_in, int H, int W, ptrdiff_t pitch, int bs, int mode, double param,
                            unsigned flags, int16_t *d_out, jpegx_stream_t stream)
 {
-    if (bs != 1 && bs != 2) return fail(JPEGX_E_UNSUPPORTED, "uint8 forward supports block_size 1 and 2");
+    if (bs != 1 && bs != 2 && bs != 4) return fail(JPEGX_E_UNSUPPORTED, "uint8 forward supports block_size 1, 2 and 4");
     int rc = check_plane(d_in, d_out, H, W, pitch / bs, 1);
     if (rc) return rc;
     if (pitch < (ptrdiff_t)W * bs || (pitch % 16) != 0 || !aligned16(d_in) || !aligned16(d_out))
@@ -733,7 +795,8 @@ int jpegx_forward_fused_u8(const uint8_t *d_in, int H, int W, ptrdiff_t pitch, i
     do { if (nt) hipLaunchKernelGGL((k_forward_fused_u8<DC, BSV, true>), grid, block, 0, st, d_in, (size_t)pitch, wb, nblk, qp, d_out, g_counters); \
          else hipLaunchKernelGGL((k_forward_fused_u8<DC, BSV, false>), grid, block, 0, st, d_in, (size_t)pitch, wb, nblk, qp, d_out, g_counters); } while (0)
     if (bs == 1) { if (dc_exact) JPEGX_LU8(true, 1); else JPEGX_LU8(false, 1); }
-    else { if (dc_exact) JPEGX_LU8(true, 2); else JPEGX_LU8(false, 2); }
+    else if (bs == 2) { if (dc_exact) JPEGX_LU8(true, 2); else JPEGX_LU8(false, 2); }
+    else { if (dc_exact) JPEGX_LU8(true, 4); else JPEGX_LU8(false, 4); }
 #undef JPEGX_LU8
     HIP_TRY(hipGetLastError());
     return JPEGX_OK;

@@ -241,8 +241,8 @@ def forward_fused_u8_device(in_ptr, height, width, out_ptr, mode="qtable", param
 
 
 def u8_path_ok(width_out, pool, pitch_bytes):
-    """Shapes the uint8 kernels accept: block_size 1 (W % 16 == 0) or 2, 16-byte aligned rows."""
-    return pool in (1, 2) and pitch_bytes % 16 == 0 and (pool == 2 or width_out % 16 == 0)
+    """Shapes the uint8 kernels accept: block_size 1 (W % 16 == 0), 2 or 4, 16-byte aligned rows."""
+    return pool in (1, 2, 4) and pitch_bytes % 16 == 0 and (pool > 1 or width_out % 16 == 0)
 
 
 def inverse_fused_device(in_ptr, height, width, out_ptr, mode="qtable", param=0.0, flags=0, out_type=OUT_F32,

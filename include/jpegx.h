@@ -125,8 +125,8 @@ int jpegx_forward_fused_pooled(const float *d_in, int H, int W, ptrdiff_t pitch,
                                double param, unsigned flags, int16_t *d_out, jpegx_stream_t stream);
 
 /* The same on uint8 planes -- the form in which image bands arrive (util.band_to_array,
- * util.py:110-112): d_in is [H*bs][pitch] bytes, bs in {1,2} (bs = 2 fuses the 2x2 mean of
- * pipeline/subsampling.py:9-11).  Reads 64 (256) bytes per block instead of 256 (1024).
+ * util.py:110-112): d_in is [H*bs][pitch] bytes, bs in {1,2,4} (bs > 1 fuses the bs x bs mean of
+ * pipeline/subsampling.py:9-11).  Reads 64 bs^2 bytes per block instead of 256 bs^2.
  * bs = 1 needs W % 16 == 0; pitch in BYTES, a multiple of 16.                                  */
 int jpegx_forward_fused_u8(const uint8_t *d_in, int H, int W, ptrdiff_t pitch, int bs, int mode,
                            double param, unsigned flags, int16_t *d_out, jpegx_stream_t stream);

@@ -359,7 +359,7 @@ def test_pooled_and_inflated_with_padded_pitches(gpu):
     assert np.all(got[:, w * bs:] == 7)
 
 
-@pytest.mark.parametrize("bs", [1, 2])
+@pytest.mark.parametrize("bs", [1, 2, 4])
 def test_forward_u8_input(gpu, golden, bs):
     """uint8 planes (with the 2x2 mean fused for bs=2): same integers as the fp32 path and the oracle."""
     for h, w in ((64, 512), (24, 48), (8, 16), (136, 1040)):
@@ -369,9 +369,10 @@ def test_forward_u8_input(gpu, golden, bs):
             want = oracle.forward_f32(pre, mode, param)
             assert np.array_equal(gpu.forward_fused_u8(raw, bs, mode, param), want), (h, w, mode)
             assert np.array_equal(gpu.forward_fused_u8(raw, bs, mode, param, flags_extra=0x100), want)
-    c = golden("ties128" if bs == 1 else "pooled128")
-    assert np.array_equal(gpu.forward_fused_u8(c["input"].astype(np.uint8), bs, "qtable"), c["zz_qtable"])
-    assert gpu.compress_plane(c["input"].astype(np.uint8), bs, "qtable") == oracle.rle_bytestream(c["zz_qtable"])
+    if bs < 4:
+        c = golden("ties128" if bs == 1 else "pooled128")
+        assert np.array_equal(gpu.forward_fused_u8(c["input"].astype(np.uint8), bs, "qtable"), c["zz_qtable"])
+        assert gpu.compress_plane(c["input"].astype(np.uint8), bs, "qtable") == oracle.rle_bytestream(c["zz_qtable"])
     if bs == 1:
         with pytest.raises(gpu.JpegxError):
             gpu.forward_fused_u8(np.zeros((8, 8), np.uint8), 1)          # W % 16 != 0
