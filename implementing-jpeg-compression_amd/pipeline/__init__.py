@@ -137,10 +137,20 @@ def _front_end_fused(band, config, with_entropy):
     if band.min() < 0 or band.max() > 255:
         return None
     padded = band if bs == 1 else padding.Padding(config).execute(band)
-    if padded.shape[0] % (8 * bs) or padded.shape[1] % (8 * bs):
-        return None
     import jpegx
     mode, param = config.quantization.gpu_mode()
+    if padded.shape[0] % (8 * bs) or padded.shape[1] % (8 * bs):
+        # DCT padding is needed: it replicates POOLED edge samples (dct_padding.py:8-9), so pool on
+        # the host first (steps 1-3), then the device does steps 4-8 on the padded plane
+        pre = padded
+        for cls in (subsampling.SubSampling, dct_padding.DCTPadding, normalization.Normalization):
+            pre = cls(config).execute(pre)
+        if not np.array_equal(pre.astype(np.float32).astype(np.float64), pre):
+            return None
+        plane = pre.astype(np.uint8) if np.array_equal(pre, np.rint(pre)) else pre.astype(np.float32)
+        if with_entropy:
+            return jpegx.compress_plane(plane, 1, mode, param)
+        return jpegx.forward_fused(plane.astype(np.float32), mode, param, pixel_input=True).astype(np.float64)
     if with_entropy:
         return jpegx.compress_plane(padded, bs, mode, param)      # uint8 upload when the shape allows
     return jpegx.forward_fused_pooled(padded.astype(np.float32), bs, mode, param, pixel_input=True).astype(np.float64)
