@@ -14,16 +14,36 @@ extern "C" void jpegx_internal_set_error(const char *msg);
 
 namespace {
 
+// MSB-first bit reader over the byte stream with a 64-bit window (refilled a byte at a time)
 struct BitReader {
     const uint8_t *p;
-    size_t nbits, pos;
-    bool take(int n, unsigned *out)      // n <= 16 bits, MSB first
+    size_t nbytes, next = 0;       // next byte to load into the window
+    uint64_t window = 0;           // the upcoming bits, left-aligned
+    int have = 0;                  // valid bits in the window
+
+    void refill()
     {
-        if (pos + (size_t)n > nbits) return false;
-        unsigned v = 0;
-        for (int i = 0; i < n; ++i, ++pos) v = (v << 1) | ((p[pos >> 3] >> (7 - (pos & 7))) & 1u);
-        *out = v;
+        while (have <= 56 && next < nbytes) {
+            window |= (uint64_t)p[next++] << (56 - have);
+            have += 8;
+        }
+    }
+    bool take(int n, unsigned *out)      // 1 <= n <= 16
+    {
+        if (have < n) {
+            refill();
+            if (have < n) return false;
+        }
+        *out = (unsigned)(window >> (64 - n));
+        window <<= n;
+        have -= n;
         return true;
+    }
+    void align_to_byte()                 // drop the zero padding after an EOB
+    {
+        const int drop = have & 7;       // bits consumed so far are a multiple of 8 iff `have` is
+        window <<= drop;
+        have -= drop;
     }
 };
 
@@ -39,7 +59,7 @@ extern "C" int jpegx_host_entropy_decode(const uint8_t *h_bytes, size_t nbytes, 
 {
     if (!h_bytes || !h_zz) return fail("null host pointer");
     if (nblocks <= 0) return fail("block count must be positive");
-    BitReader br{h_bytes, nbytes * 8, 0};
+    BitReader br{h_bytes, nbytes};
     for (long long b = 0; b < nblocks; ++b) {
         int16_t *blk = h_zz + b * 64;
         int n = 0;                                   // coefficients written so far
@@ -48,7 +68,7 @@ extern "C" int jpegx_host_entropy_decode(const uint8_t *h_bytes, size_t nbytes, 
             if (!br.take(4, &run) || !br.take(4, &size)) return fail("entropy stream ends inside a block");
             if (run == 0 && size == 0) {             // EOB: zero fill, skip the byte padding
                 for (; n < 64; ++n) blk[n] = 0;
-                br.pos = (br.pos + 7) & ~(size_t)7;
+                br.align_to_byte();
                 break;
             }
             if (run == 15 && size == 0) {            // zero chain: FIFTEEN zeros (util.py:134-154)

@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Wall time of the reference-compatible host API (NumPy band in, bytes out and back) on one
+4096x4096 band: what a user of compress_band / decompress_band sees, PCIe and host parsing included."""
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "implementing-jpeg-compression_amd"))
+import jpegx  # noqa: E402
+import pipeline  # noqa: E402
+
+
+def best(fn, n=3):
+    ts = []
+    for _ in range(n):
+        t0 = time.perf_counter()
+        out = fn()
+        ts.append(time.perf_counter() - t0)
+    return min(ts), out
+
+
+def main():
+    jpegx.require_device()
+    size = 4096
+    for kind in ("smooth", "noise"):
+        band = jpegx.synth.generate_plane(kind, size, size, seed=1, dtype=np.int64)
+        for bs in (1, 2, 4):
+            cfg = pipeline.Configuration(width=size, height=size, block_size=bs, dct_size=8,
+                                         quantization=pipeline.QuantizationMethod("qtable"))
+            pipeline.compress_band(band, cfg)                      # warm-up (allocations, clocks)
+            tc, blob = best(lambda: pipeline.compress_band(band, cfg))
+            td, rec = best(lambda: pipeline.decompress_band(blob, cfg))
+            nblk = (size // bs // 8) ** 2
+            err = float(np.abs(rec - band).mean())
+            print("%-6s block_size %d: compress_band %.1f ms (%.1f Mblocks/s, %d bytes), decompress_band %.1f ms, "
+                  "mean abs error %.2f" % (kind, bs, tc * 1e3, nblk / tc / 1e6, len(blob), td * 1e3, err), flush=True)
+
+
+if __name__ == "__main__":
+    main()
