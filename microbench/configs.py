@@ -41,21 +41,57 @@ def timed(fn, rounds=7, iters=10):
     return statistics.median(ts)
 
 
-def c3(kind):
+def timed_wall(fn, rounds=7, iters=20):
+    """Host wall clock around `iters` enqueues + one device synchronize (for multi-stream steps)."""
+    import time
+    L = jpegx.lib()
+    for _ in range(40):
+        fn()
+    jpegx.check(L.jpegx_device_synchronize())
+    ts = []
+    for _ in range(rounds):
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            fn()
+        jpegx.check(L.jpegx_device_synchronize())
+        ts.append((time.perf_counter() - t0) * 1e3 / iters)
+    return statistics.median(ts)
+
+
+def c3(kind, layout="separate"):
+    """layout: "separate" = three launches, one per plane (Cb, Cr 4096 waves each: a single generation of
+    workgroups on 256 CUs); "stacked" = Cb and Cr stored one above the other and transformed by ONE launch;
+    "streams" = stacked chroma on a second HIP stream, concurrent with the Y launch (wall-clock timed)."""
     n = 8192
-    ybuf, cb, cr = (jpegx.DeviceBuffer(n * n * 4) for _ in range(3))
-    for i, b in enumerate((ybuf, cb, cr)):
-        jpegx.generate_plane_device(b.ptr, n, n, kind, seed=0, plane=i)
-    zy, zcb, zcr = jpegx.DeviceBuffer(n * n * 2), jpegx.DeviceBuffer(n * n // 2), jpegx.DeviceBuffer(n * n // 2)
+    ybuf = jpegx.DeviceBuffer(n * n * 4)
+    chroma = jpegx.DeviceBuffer(2 * n * n * 4)             # Cb rows, then Cr rows
+    jpegx.generate_plane_device(ybuf.ptr, n, n, kind, seed=0, plane=0)
+    jpegx.generate_plane_device(chroma.ptr, n, n, kind, seed=0, plane=1)
+    jpegx.generate_plane_device(chroma.ptr + n * n * 4, n, n, kind, seed=0, plane=2)
+    zy, zc = jpegx.DeviceBuffer(n * n * 2), jpegx.DeviceBuffer(n * n)
+
+    streams = [None, None]
+    if layout == "streams":
+        import ctypes
+        for i in range(2):
+            h = ctypes.c_void_p()
+            jpegx.check(jpegx.lib().jpegx_stream_create(ctypes.byref(h)))
+            streams[i] = h.value
 
     def step():
-        jpegx.forward_fused_device(ybuf.ptr, n, n, zy.ptr, "qtable", 0.0, PIX)
-        jpegx.forward_fused_device(cb.ptr, n // 2, n // 2, zcb.ptr, "qtable", 0.0, PIX, pool=2)
-        jpegx.forward_fused_device(cr.ptr, n // 2, n // 2, zcr.ptr, "qtable", 0.0, PIX, pool=2)
-    ms = timed(step)
+        jpegx.forward_fused_device(ybuf.ptr, n, n, zy.ptr, "qtable", 0.0, PIX, stream=streams[0])
+        if layout == "streams":
+            jpegx.forward_fused_device(chroma.ptr, n, n // 2, zc.ptr, "qtable", 0.0, PIX, pool=2, stream=streams[1])
+        elif layout == "stacked":
+            jpegx.forward_fused_device(chroma.ptr, n, n // 2, zc.ptr, "qtable", 0.0, PIX, pool=2)
+        else:
+            jpegx.forward_fused_device(chroma.ptr, n // 2, n // 2, zc.ptr, "qtable", 0.0, PIX, pool=2)
+            jpegx.forward_fused_device(chroma.ptr + n * n * 4, n // 2, n // 2, zc.ptr + n * n // 2, "qtable", 0.0, PIX, pool=2)
+    ms = timed_wall(step) if layout == "streams" else timed(step)
     blocks = (n // 8) ** 2 + 2 * (n // 16) ** 2
     nbytes = (n // 8) ** 2 * 384 + 2 * (n // 16) ** 2 * 1152
-    return {"config": "c3 8192x8192 YCbCr 4:2:0 forward (Y + 2x pooled chroma)", "kind": kind, "ms": round(ms, 4),
+    return {"config": "c3 8192x8192 YCbCr 4:2:0 forward (Y + 2x pooled chroma, %s chroma launches)" % layout,
+            "kind": kind, "ms": round(ms, 4),
             "Mblocks_per_s": round(blocks / ms / 1e3, 1), "GBps": round(nbytes / ms / 1e6, 1),
             "frac_of_8TBps": round(nbytes / ms / 1e6 / 8000, 4), "blocks": blocks, "bytes": nbytes}
 
@@ -135,7 +171,9 @@ def main():
     jpegx.require_device()
     for kind in ("smooth", "noise"):
         if "c3" in a.what:
-            print(json.dumps(c3(kind)), flush=True)
+            print(json.dumps(c3(kind, "separate")), flush=True)
+            print(json.dumps(c3(kind, "stacked")), flush=True)
+            print(json.dumps(c3(kind, "streams")), flush=True)
         if "c4" in a.what:
             print(json.dumps(c4(kind)), flush=True)
         if "inv" in a.what:
