@@ -1,24 +1,35 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the fused forward path (8x8 DCT + quantise + zigzag).
 
-Contract (driver): ``python bench.py --gpus N --steps K --warmup W`` prints ONE JSON line on
-rank 0.  For N > 1 it is launched under ``torch.distributed.run`` (one process per GPU, RCCL).
+Contract (driver): ``python bench.py --gpus N --steps K --warmup W`` prints ONE JSON line on rank 0.
+It works both ways for N > 1: started bare it launches its own N rank processes
+(jpegx.multigpu.launch_ranks, before anything touches the GPU) and exits with their status; started
+under ``python -m torch.distributed.run --nproc-per-node N`` it finds RANK / WORLD_SIZE in the
+environment and is one of the ranks.  No PyTorch anywhere: ranks talk through a small TCP control
+plane (jpegx.multigpu.ControlPlane) and move bulk data with RCCL through libjpegx (jpegx_comm_*).
 
-Workload (BASELINE.json configs[1]): 4096x4096 synthetic Y planes, fp32, JPEG luminance table.
-A *step* is one fused-kernel launch over a batch of ``--planes`` DISTINCT 4096x4096 planes that
-are already resident in HBM (stacked as one tall plane = one launch).  16 planes = 1 GiB read +
-0.5 GiB written per step, far beyond the 256 MiB Infinity Cache, so the stream comes from HBM.
-Weak scaling: every rank owns its own batch (planes are independent units, no data-path
-collective in the timed region); the RCCL gather of the coefficient stream to rank 0 is timed
-separately and reported under "gather".
+Workload (BASELINE.json configs[4], whose per-GPU unit is configs[1]): a FIXED batch of 1024
+independent 4096x4096 synthetic Y planes (fp32, integer valued, generated on the device), JPEG
+luminance table; rank r owns the contiguous plane range shard_planes(1024, N, r) -- all 1024 at N = 1
+(64 GiB in + 32 GiB out of the 288 GB), 128 at N = 8.  A *step* is one pass of the fused forward
+kernel over the rank's planes, resident in HBM, as ONE launch (the planes are stacked into one tall
+plane).  Strong scaling: the batch is fixed, per-GPU work shrinks as 1024/N.
 
-value    = blocks processed by all ranks / max-over-ranks wall time of the K steps   [Mblocks/s]
-roofline = algorithmic bytes (384 B per block: 256 B fp32 read + 128 B int16 written) per launch
-           divided by the average launch duration measured with HIP events on the launch stream.
-cpu_baseline (rank 0, N=1 only) = the faithful Python/NumPy per-block loop restatement of the
-           reference (oracle/ref_loop.py, 1 core) on one plane; the C oracle's rate is given too.
+value     = blocks of the whole batch x K / max-over-ranks wall time of the K steps   [Mblocks/s]
+            (compute phase: no data-path collective is needed, blocks are independent)
+roofline  = algorithmic bytes (384 B per block: 256 B fp32 read + 128 B int16 written) per launch
+            divided by the average launch duration from HIP events on the launch stream.
+gather / end_to_end (N > 1) = the one exchange of the path: the int16 stream goes to rank 0 with
+            grouped ncclSend/ncclRecv, chunked per --gather-chunk planes on a second stream behind
+            per-chunk events, i.e. overlapped with the transform.  Reported next to `value`, never
+            folded into it: root ingress is xGMI-bound (7 links x ~153 GB/s).
+configs   (N = 1) = BASELINE.json configs[2] (8192^2 YCbCr 4:2:0) and configs[3] (4096^2 round trip
+            with PSNR), timed in the same run with their own algorithmic bytes.
+cpu_baseline (N = 1) = the faithful Python/NumPy per-block loop restatement of the reference
+            (oracle/ref_loop.py, 1 core) on three planes; the C oracle's rate is given too.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -32,30 +43,44 @@ sys.path.insert(0, os.path.join(REPO, "implementing-jpeg-compression_amd"))
 
 BYTES_PER_BLOCK = 384          # 64*4 B read + 64*2 B written
 HBM_PEAK_GBPS = 8000.0         # MI355X_MICROARCH.md: 8 TB/s spec
+XGMI_ROOT_INGRESS_GBPS = 7 * 153
+FORWARD_SOURCES = ("implementing-jpeg-compression_amd/csrc/jpegx_forward.hip", "implementing-jpeg-compression_amd/csrc/jpegx_device.h",
+                   "implementing-jpeg-compression_amd/csrc/jpegx_math.h", "implementing-jpeg-compression_amd/csrc/jpegx_internal.h",
+                   "include/jpegx_tables.inc")
 
 
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--planes", type=int, default=16, help="distinct 4096x4096 planes per step and rank")
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--planes-total", type=int, default=1024, help="size of the fixed batch (configs[4]: 1024)")
     ap.add_argument("--size", type=int, default=4096)
     ap.add_argument("--kind", default="noise", choices=["noise", "smooth"],
                     help="synthetic plane generator (noise = worst case for rounding ties)")
     ap.add_argument("--mode", default="qtable", choices=["qtable", "none", "divide", "discard"])
     ap.add_argument("--param", type=float, default=0.0)
     ap.add_argument("--spinup-ms", type=float, default=60.0,
-                    help="untimed launches before the W warm-up steps so that the GPU leaves its idle clocks "
-                         "(a launch is ~0.25 ms; without this the first ~10 ms run ~10 %% slower)")
-    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the control flow)")
+                    help="untimed launches before the W warm-up steps so that the GPU leaves its idle clocks")
+    ap.add_argument("--gather-chunk", type=int, default=4, help="planes per send/recv round of the overlapped gather")
     ap.add_argument("--share-device", action="store_true",
-                    help="rehearsal only: every rank uses GPU 0 (needs --backend gloo)")
+                    help="rehearsal on ONE GPU: every rank uses GPU 0 and a 1-rank RCCL communicator "
+                         "(loop-back send/recv); exercises launcher, control plane, events and streams")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU work at all: launcher + control plane + shard plan only (CPU tests)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the configs[2]/[3] legs at N = 1")
     return ap.parse_args()
+
+
+def forward_source_hash():
+    h = hashlib.sha256()
+    for rel in FORWARD_SOURCES:
+        with open(os.path.join(REPO, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 def cpu_baseline(size, kind, sample_planes=3):
@@ -105,54 +130,172 @@ def cpu_baseline(size, kind, sample_planes=3):
     }
 
 
+# --------------------------------------------------------------------------------------------------
+# the other single-GPU configs of BASELINE.json, timed in the same run (N = 1 only)
+# --------------------------------------------------------------------------------------------------
+def _timed_launches(jpegx, fn, iters, warm=5):
+    """Average duration of `fn` (enqueue-only, default stream) over `iters` back-to-back calls, HIP events."""
+    L = jpegx.lib()
+    for _ in range(warm):
+        fn()
+    e0, e1 = jpegx.Event(), jpegx.Event()
+    jpegx.check(L.jpegx_device_synchronize(), "sync")
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_ms(e1) / iters
+
+
+def config3(jpegx, kind, iters, verify):
+    """configs[2]: 8192x8192 YCbCr 4:2:0 -- Y plane + Cb, Cr with the 2x2 SubSampling mean fused
+    (pipeline/subsampling.py:9-11), all three planes in ONE launch (jpegx_forward_fused_planes).
+    Algorithmic bytes: Y 384 B/block, chroma 4 x 256 B read + 128 B written."""
+    n = 8192
+    ybuf, cb, cr = jpegx.DeviceBuffer(n * n * 4), jpegx.DeviceBuffer(n * n * 4), jpegx.DeviceBuffer(n * n * 4)
+    for i, b in enumerate((ybuf, cb, cr)):
+        jpegx.generate_plane_device(b.ptr, n, n, kind, seed=0, plane=i)
+    zy, zcb, zcr = jpegx.DeviceBuffer(n * n * 2), jpegx.DeviceBuffer(n * n // 2), jpegx.DeviceBuffer(n * n // 2)
+    planes = [(ybuf.ptr, n, n, n, 1, zy.ptr), (cb.ptr, n // 2, n // 2, n, 2, zcb.ptr), (cr.ptr, n // 2, n // 2, n, 2, zcr.ptr)]
+
+    def step():
+        jpegx.forward_fused_planes_device(planes, "qtable", 0.0, jpegx.F_PIXEL_INPUT)
+    ms = _timed_launches(jpegx, step, iters)
+    blocks = (n // 8) ** 2 + 2 * (n // 16) ** 2
+    nbytes = (n // 8) ** 2 * 384 + 2 * (n // 16) ** 2 * 1152
+    res = {"ms": round(ms, 4), "blocks": blocks, "algorithmic_bytes": nbytes, "Mblocks_per_s": round(blocks / ms / 1e3, 1),
+           "GBps": round(nbytes / ms / 1e6, 1), "frac": round(nbytes / ms / 1e6 / HBM_PEAK_GBPS, 4)}
+    if verify:
+        import oracle
+        from jpegx import synth
+        rows = 256
+        ok = np.array_equal(zy.download((rows // 8, n // 8, 64), np.int16),
+                            oracle.forward_f32(synth.generate_plane(kind, rows, n, seed=0, plane=0), "qtable"))
+        for i, z in ((1, zcb), (2, zcr)):
+            pooled = oracle.mean_pool(synth.generate_plane(kind, 2 * rows, n, seed=0, plane=i).astype(np.float64), 2)
+            ok = ok and np.array_equal(z.download((rows // 8, n // 16, 64), np.int16), oracle.forward_f32(pooled, "qtable"))
+        res["verified_vs_oracle"] = bool(ok)
+    for b in (ybuf, cb, cr, zy, zcb, zcr):
+        b.free()
+    return res
+
+
+def config4(jpegx, kind, iters, verify, planes=16):
+    """configs[3]: round trip of 4096x4096 planes -- fused forward, then fused inverse (un-zigzag +
+    dequantise + IDCT + np.round + clamp, fp32 out); 768 algorithmic bytes per block; PSNR vs input."""
+    n = 4096
+    H = n * planes
+    src, rec, zz = jpegx.DeviceBuffer(H * n * 4), jpegx.DeviceBuffer(H * n * 4), jpegx.DeviceBuffer(H * n * 2)
+    for p in range(planes):
+        jpegx.generate_plane_device(src.ptr + p * n * n * 4, n, n, kind, seed=0, plane=p)
+
+    def fwd():
+        jpegx.forward_fused_device(src.ptr, H, n, zz.ptr, "qtable", 0.0, jpegx.F_PIXEL_INPUT)
+
+    def inv():
+        jpegx.inverse_fused_device(zz.ptr, H, n, rec.ptr, "qtable", 0.0, jpegx.F_CLAMP_U8, out_type=jpegx.OUT_F32)
+
+    def both():
+        fwd()
+        inv()
+    ms = _timed_launches(jpegx, both, iters)
+    ms_inv = _timed_launches(jpegx, inv, iters)
+    cnt = jpegx.DeviceBuffer(16)
+    L = jpegx.lib()
+    jpegx.check(L.jpegx_memset(cnt.ptr, 0, 16, None), "memset")
+    jpegx.check(L.jpegx_set_debug_counters(cnt.ptr), "counters")
+    inv()
+    jpegx.check(L.jpegx_device_synchronize(), "sync")
+    jpegx.check(L.jpegx_set_debug_counters(None), "counters")
+    census = cnt.download((2,), np.uint64)
+    blocks = (H // 8) * (n // 8)
+    a = src.download((n, n), np.float32).astype(np.float64)
+    b = rec.download((n, n), np.float32).astype(np.float64)
+    res = {"ms": round(ms, 4), "blocks": blocks, "algorithmic_bytes": blocks * 768, "Mblocks_per_s": round(blocks / ms / 1e3, 1),
+           "GBps": round(blocks * 768 / ms / 1e6, 1), "frac": round(blocks * 768 / ms / 1e6 / HBM_PEAK_GBPS, 4),
+           "psnr_dB": round(float(10 * np.log10(255.0 ** 2 / np.mean((a - b) ** 2))), 3),
+           "inverse_only": {"ms": round(ms_inv, 4), "GBps": round(blocks * 384 / ms_inv / 1e6, 1),
+                            "frac": round(blocks * 384 / ms_inv / 1e6 / HBM_PEAK_GBPS, 4),
+                            "exact_tier_block_fraction": round(float(census[0]) / max(1.0, float(census[1])), 5)}}
+    if verify:
+        import oracle
+        sub = a[:512, :1024].astype(np.float32)
+        ref = np.clip(oracle.inverse_i16(oracle.forward_f32(sub, "qtable"), "qtable"), 0, 255)
+        res["verified_vs_oracle"] = bool(np.array_equal(ref, b[:512, :1024]))
+    for x in (src, rec, zz, cnt):
+        x.free()
+    return res
+
+
+# --------------------------------------------------------------------------------------------------
 def main():
     args = parse_args()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
-                         % (args.gpus, args.gpus))
+    from jpegx import multigpu
+    in_job = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if not in_job and args.gpus > 1:
+        # bare `python bench.py --gpus N`: become the launcher (nothing has touched the GPU yet)
+        sys.exit(multigpu.launch_ranks(args.gpus, [os.path.abspath(__file__)] + sys.argv[1:]))
+    rank, local_rank, world = multigpu.rank_env()
+    if args.gpus != world:
+        raise SystemExit("bench.py --gpus %d was started inside a job of %d ranks" % (args.gpus, world))
+    ctl = multigpu.ControlPlane(rank, world)
+    try:
+        run(args, rank, local_rank, world, ctl)
+    finally:
+        ctl.close()
 
-    # torch (only needed for the N > 1 process group) must be imported BEFORE libjpegx.so is loaded so
-    # that both resolve to ONE HIP runtime (torch bundles its own libamdhip64; loading /opt/rocm's first
-    # leaves torch without devices -- measured on the GPU box).
-    dist = None
-    torch = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-        if args.share_device:
-            local_rank = 0
-        torch.cuda.set_device(local_rank)
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group("gloo")
+
+def run(args, rank, local_rank, world, ctl):
+    from jpegx import multigpu
+    size, total_planes = args.size, args.planes_total
+    spans = [multigpu.shard_planes(total_planes, world, r) for r in range(world)]
+    lo, hi = spans[rank]
+    planes = hi - lo
+    if planes < 1:
+        raise SystemExit("rank %d owns no plane (batch of %d over %d ranks)" % (rank, total_planes, world))
+    H, W = size * planes, size
+    blocks_per_step = (H // 8) * (W // 8)
+    total_blocks_per_step = (size // 8) ** 2 * total_planes
+    plane_in, plane_out = size * size * 4, size * size * 2
+
+    if args.dry_run:
+        seen = ctl.allgather([rank, lo, hi, os.getpid()])
+        ident = ctl.bcast_bytes(bytes(range(128)) if rank == 0 else None)
+        ok = ctl.all_ok(ident == bytes(range(128)) and seen[rank][0] == rank)
+        t = ctl.allreduce_max(float(rank))
+        ctl.barrier()
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "shards": [s[1:3] for s in seen], "all_ok": ok,
+                              "max_rank": t, "launcher": os.environ.get("JPEGX_LAUNCHER", "external")}), flush=True)
+        return
+
     import jpegx
     jpegx.require_device()
     L = jpegx.lib()
-    jpegx.check(L.jpegx_set_device(local_rank if world > 1 else 0), "jpegx_set_device")
+    device = 0 if (args.share_device or world == 1) else local_rank
+    jpegx.check(L.jpegx_set_device(device), "jpegx_set_device")
 
-    size, planes = args.size, args.planes
-    H, W = size * planes, size
-    blocks_per_step = (H // 8) * (W // 8)
-    in_bytes, out_bytes = H * W * 4, H * W * 2
-
-    if torch is not None:
-        t_in = torch.empty(H * W, dtype=torch.float32, device="cuda")
-        t_out = torch.empty(H * W, dtype=torch.int16, device="cuda")
-        in_ptr, out_ptr = t_in.data_ptr(), t_out.data_ptr()
-        stream = torch.cuda.current_stream().cuda_stream or None
+    gathering = world > 1 and not args.no_gather
+    loopback = bool(args.share_device)
+    # root keeps the whole batch's stream (its own planes are written in place); loop-back rehearsal: a
+    # second buffer of the rank's own size stands in for the root's
+    b_in = jpegx.DeviceBuffer(planes * plane_in)
+    if gathering and rank == 0 and not loopback:
+        b_root = jpegx.DeviceBuffer(total_planes * plane_out)
+        out_ptr, root_ptr = b_root.ptr + lo * plane_out, b_root.ptr
     else:
-        b_in, b_out = jpegx.DeviceBuffer(in_bytes), jpegx.DeviceBuffer(out_bytes)
-        in_ptr, out_ptr = b_in.ptr, b_out.ptr
-        stream = None
+        b_out = jpegx.DeviceBuffer(planes * plane_out)
+        out_ptr, root_ptr = b_out.ptr, None
+        if gathering and loopback:
+            b_root = jpegx.DeviceBuffer(planes * plane_out)
+            root_ptr = b_root.ptr - lo * plane_out     # plane p of the batch at root_ptr + p * plane_out
+    in_ptr = b_in.ptr
+    stream = None
 
-    # synthetic planes generated on the device; plane ids are globally unique across ranks
+    # synthetic planes generated on the device; plane ids are those of the whole batch
     for p in range(planes):
-        jpegx.generate_plane_device(in_ptr + p * size * size * 4, size, size, args.kind, seed=0,
-                                    plane=rank * planes + p, stream=stream)
+        jpegx.generate_plane_device(in_ptr + p * plane_in, size, size, args.kind, seed=0, plane=lo + p, stream=stream)
     jpegx.check(L.jpegx_stream_synchronize(stream), "sync")
 
     flags = jpegx.F_PIXEL_INPUT
@@ -162,16 +305,12 @@ def main():
 
     def barrier():
         jpegx.check(L.jpegx_device_synchronize(), "sync")
-        if dist is not None:
-            dist.barrier()
-            jpegx.check(L.jpegx_device_synchronize(), "sync")
+        ctl.barrier()
 
-    # clock spin-up (untimed, not part of W): the device ramps from idle clocks over the first
-    # ~10 ms of work; measured 0.283 ms/launch right after idle vs 0.253 ms once ramped.
+    # clock spin-up (untimed, not part of W): the device ramps from idle clocks over the first ~10 ms
     t_spin = time.perf_counter()
     while (time.perf_counter() - t_spin) * 1e3 < args.spinup_ms:
-        for _ in range(8):
-            step()
+        step()
         jpegx.check(L.jpegx_stream_synchronize(stream), "sync")
     for _ in range(args.warmup):
         step()
@@ -186,14 +325,8 @@ def main():
     t_local = time.perf_counter() - t0
     kernel_ms = ev0.elapsed_ms(ev1) / args.steps     # average launch duration on the launch stream
     barrier()
-
-    t_max = t_local
-    if dist is not None:
-        tt = torch.tensor([t_local], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        t_max = float(tt.item())
-    total_blocks = blocks_per_step * args.steps * world
-    value = total_blocks / t_max / 1e6
+    t_max = ctl.allreduce_max(t_local)
+    value = total_blocks_per_step * args.steps / t_max / 1e6
 
     # --- exact-tier census (untimed): how many blocks took the float64 path -----------------------
     cnt = jpegx.DeviceBuffer(16)
@@ -205,124 +338,192 @@ def main():
     census = cnt.download((2,), np.uint64)
     exact_frac = float(census[0]) / max(1.0, float(census[1]))
 
-    # --- verification against the oracle (untimed, rank-local first plane) ------------------------
+    # --- verification against the oracle (untimed): slices of the rank's first and last plane ------
     verified = None
     if not args.no_verify:
         import oracle
         from jpegx import synth
-        vh = min(size, 1024)
-        want = oracle.forward_f32(synth.generate_plane(args.kind, vh, size, seed=0, plane=rank * planes),
-                                  args.mode, args.param)
-        if torch is not None:
-            got = t_out[: vh * size].cpu().numpy().reshape(vh // 8, size // 8, 64)
-        else:
-            got = b_out.download((vh // 8, size // 8, 64), np.int16)
-        verified = bool(np.array_equal(got, want))
+        vh = min(size, 512)
+        verified = True
+        for p in sorted({0, planes - 1}):
+            want = oracle.forward_f32(synth.generate_plane(args.kind, vh, size, seed=0, plane=lo + p), args.mode, args.param)
+            got = np.empty((vh // 8, size // 8, 64), np.int16)
+            jpegx.check(L.jpegx_memcpy_d2h(got.ctypes.data, out_ptr + p * plane_out, got.nbytes, None), "d2h")
+            jpegx.check(L.jpegx_device_synchronize(), "sync")
+            verified = verified and bool(np.array_equal(got, want))
+        verified = bool(all(ctl.allgather(verified)))
 
-    # --- RCCL gather of the coefficient stream to rank 0 (separately timed) -----------------------
-    gather = None
-    if dist is not None and not args.no_gather:
-        from jpegx.multigpu import gather_stream
-        try:
-            gl = gather_stream(t_out, dst=0)                   # warm-up / connection setup
-            torch.cuda.synchronize()
-            dist.barrier()
-            tg = time.perf_counter()
-            gl = gather_stream(t_out, dst=0)
-            torch.cuda.synchronize()
-            dist.barrier()
-            tg = time.perf_counter() - tg
-            tgt = torch.tensor([tg], dtype=torch.float64, device="cuda")
-            dist.all_reduce(tgt, op=dist.ReduceOp.MAX)
-            tg = float(tgt.item())
-            ok = True
-            if rank == 0:
-                ok = bool(torch.equal(gl[0], t_out.reshape(-1))) and len(gl) == world
-            gather = {"ms": round(tg * 1e3, 3), "bytes_into_root": out_bytes * (world - 1),
-                      "GBps_into_root": round(out_bytes * (world - 1) / tg / 1e9, 2),
-                      "xgmi_bound_GBps": 7 * 153, "root_copy_ok": ok,
-                      "note": "jpegx.multigpu.gather_stream: torch.distributed.gather (RCCL) of every rank's int16 "
-                              "stream as raw bytes; not part of `value` (compute phase), see DESIGN.md multi-GPU"}
-        except Exception as exc:   # the compute-phase result must survive a failing collective
-            gather = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
-        # The same gather after the device entropy stage (steps 7+8, jpegx_entropy_*): the stream that
-        # crosses xGMI shrinks by the compression ratio.  Untimed extra; failures are reported, not fatal.
-        try:
-            import ctypes
-            nblk = blocks_per_step
-            t_ws = torch.empty(int(L.jpegx_entropy_workspace_bytes(nblk)), dtype=torch.uint8, device="cuda")
-            jpegx.check(L.jpegx_entropy_sizes(out_ptr, nblk, t_ws.data_ptr(), stream), "jpegx_entropy_sizes")
-            tot = ctypes.c_ulonglong(0)
-            jpegx.check(L.jpegx_entropy_total(t_ws.data_ptr(), ctypes.byref(tot), stream), "jpegx_entropy_total")
-            t_comp = torch.empty(max(1, tot.value), dtype=torch.uint8, device="cuda")
-            torch.cuda.synchronize()
-            te = time.perf_counter()
-            jpegx.check(L.jpegx_entropy_sizes(out_ptr, nblk, t_ws.data_ptr(), stream), "jpegx_entropy_sizes")
-            jpegx.check(L.jpegx_entropy_emit(out_ptr, nblk, t_ws.data_ptr(), t_comp.data_ptr(), stream), "jpegx_entropy_emit")
-            torch.cuda.synchronize()
-            te = time.perf_counter() - te
-            gather_stream(t_comp, dst=0)
-            torch.cuda.synchronize()
-            dist.barrier()
-            tc = time.perf_counter()
-            parts = gather_stream(t_comp, dst=0)
-            torch.cuda.synchronize()
-            dist.barrier()
-            tc = time.perf_counter() - tc
-            tct = torch.tensor([tc, float(tot.value)], dtype=torch.float64, device="cuda")
-            dist.all_reduce(tct, op=dist.ReduceOp.MAX)
-            okc = True
-            if rank == 0:
-                okc = bool(torch.equal(parts[0], t_comp)) and len(parts) == world
-            gather["compressed"] = {"ms": round(float(tct[0].item()) * 1e3, 3), "bytes_per_rank_max": int(tct[1].item()),
-                                    "ratio_vs_int16_stream": round(out_bytes / max(1.0, float(tct[1].item())), 2),
-                                    "entropy_stage_ms_this_rank": round(te * 1e3, 3), "root_copy_ok": okc}
-        except Exception as exc:
-            if gather is None:
-                gather = {}
-            gather["compressed"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
+    # --- the one exchange of the path: RCCL gather of the int16 stream to rank 0 -------------------
+    gather = end_to_end = None
+    if gathering:
+        gather, end_to_end = gather_legs(args, jpegx, multigpu, ctl, rank, world, spans, in_ptr, out_ptr, root_ptr,
+                                         plane_out, total_blocks_per_step, loopback)
 
-    # HBM traffic per launch from the committed rocprofv3 PMC passes of this same command
-    # (profiles/summarize.py; FETCH_SIZE doubled per the gfx950 correction).  Not collected live.
-    traffic = None
+    achieved = BYTES_PER_BLOCK * blocks_per_step / (kernel_ms * 1e-3) / 1e9
+    # HBM traffic per launch from the committed rocprofv3 PMC passes of this same command, accepted only
+    # while the kernel sources are the ones that were profiled (profiles/summarize.py records their hash)
+    traffic = traffic_src = None
     try:
-        with open(os.path.join(REPO, "profiles", "r01_forward_summary.json")) as f:
+        with open(os.path.join(REPO, "profiles", "r02_forward_summary.json")) as f:
             prof = json.load(f)
-        if int(prof["kernel_trace"]["grid"]) == blocks_per_step and args.mode == "qtable":
-            traffic = prof["hbm_traffic"]["total_bytes_per_launch"]
+        if prof.get("forward_source_sha16") == forward_source_hash() and args.mode == "qtable":
+            traffic = prof["hbm_traffic"]["bytes_per_block"] * blocks_per_step
+            traffic_src = "profiles/r02_forward_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel, " \
+                          "%.2f B per block, scaled to this launch's blocks)" % prof["hbm_traffic"]["bytes_per_block"]
     except Exception:
         traffic = None
-    achieved = BYTES_PER_BLOCK * blocks_per_step / (kernel_ms * 1e-3) / 1e9
     result = {
         "metric": "M 8x8 blocks/sec (DCT+quant+zigzag)",
         "value": round(value, 2), "unit": "Mblocks/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(t_max / args.steps * 1e3, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic (%s planes generated on device, integer-valued 0..255)" % args.kind,
-        "config": {"workload": "configs[1]: %dx%d synthetic Y planes, 8x8 DCT + %s quantiser + zigzag, "
-                               "fp32 in / int16 out; %d distinct planes per step and GPU (one launch)"
-                               % (size, size, args.mode, planes),
-                   "planes_per_step_per_gpu": planes, "blocks_per_step_per_gpu": blocks_per_step,
-                   "parallelism": "planes sharded per GPU, no data-path collective in the timed region"},
+        "config": {"workload": "configs[4] batch = %d x configs[1] planes (%dx%d synthetic Y, 8x8 DCT + %s quantiser + zigzag, "
+                               "fp32 in / int16 out), %s planes per GPU resident in HBM, one launch per step"
+                               % (total_planes, size, size, args.mode, "/".join(str(b - a) for a, b in spans) if world <= 8 else planes),
+                   "planes_total": total_planes, "planes_per_gpu": [b - a for a, b in spans],
+                   "blocks_per_step_total": total_blocks_per_step, "blocks_per_launch_rank0": blocks_per_step,
+                   "parallelism": "contiguous plane ranges per GPU, no data-path collective in the timed region; "
+                                  "launcher=%s" % os.environ.get("JPEGX_LAUNCHER", "external (torch.distributed.run)" if world > 1 else "none")},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                     "traffic_source": "profiles/r01_forward_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
-                                       "passes of this command; bytes per launch)" if traffic else None,
+                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                      "kernel": "k_forward_fused_strip<3,nt>", "kernel_ms": round(kernel_ms, 4),
                      "algorithmic_bytes_per_launch": BYTES_PER_BLOCK * blocks_per_step},
         "exact_tier_block_fraction": round(exact_frac, 5),
         "verified_vs_oracle": verified,
-        "device": jpegx.device_name(local_rank if world > 1 else 0),
+        "device": jpegx.device_name(device),
     }
     if gather is not None:
         result["gather"] = gather
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(size, args.kind)
+    if end_to_end is not None:
+        result["end_to_end"] = end_to_end
+    if rank == 0 and world == 1:
+        if not args.no_configs:
+            # free the batch first: the legs below allocate their own planes
+            b_in.free()
+            iters = max(10, min(50, args.steps))
+            cfg = {}
+            for name, fn in (("c3_8192_ycbcr420_forward", config3), ("c4_4096_round_trip", config4)):
+                cfg[name] = {}
+                for kind in ("noise", "smooth"):
+                    try:
+                        cfg[name][kind] = fn(jpegx, kind, iters, not args.no_verify)
+                    except Exception as exc:
+                        cfg[name][kind] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
+            result["configs"] = cfg
+        if not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(size, args.kind)
     if rank == 0:
         print(json.dumps(result), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    ctl.barrier()
+
+
+def gather_legs(args, jpegx, multigpu, ctl, rank, world, spans, in_ptr, out_ptr, root_ptr, plane_out,
+                total_blocks_per_step, loopback):
+    """(gather, end_to_end) dicts.  Rank-local preparation first, then an all-ranks ok vote, and only
+    then the RCCL calls: a rank that failed locally makes everybody skip the collective."""
+    import ctypes
+    L = jpegx.lib()
+    lo, hi = spans[rank]
+    planes = hi - lo
+    size = args.size
+    err, comm, s_comp, s_comm = None, None, None, None
+    plan = multigpu.GatherPlan(args.planes_total, world, plane_out, args.gather_chunk)
+    try:
+        jpegx.check(L.jpegx_comm_available(), "jpegx_comm_available")
+        h = ctypes.c_void_p()
+        jpegx.check(L.jpegx_stream_create(ctypes.byref(h)), "jpegx_stream_create")
+        s_comp = h.value
+        h = ctypes.c_void_p()
+        jpegx.check(L.jpegx_stream_create(ctypes.byref(h)), "jpegx_stream_create")
+        s_comm = h.value
+        events = [jpegx.Event() for _ in range(plan.rounds)]
+    except Exception as exc:
+        err = "%s: %s" % (type(exc).__name__, str(exc)[:300])
+    if not ctl.all_ok(err is None):
+        return {"error": "setup failed on some rank: %s" % ctl.allgather(err)}, None
+    try:
+        if loopback:
+            comm = multigpu.NativeComm(1, 0, lambda ident: ident)
+            view = multigpu.GatherPlan(planes, 1, plane_out, args.gather_chunk)
+            view.spans = [(lo, hi)]                      # keep batch plane numbering
+            send_root = root_ptr
+        else:
+            comm = multigpu.NativeComm(world, rank, ctl.bcast_bytes)
+            view, send_root = plan, root_ptr
+        reported = comm.count()
+    except Exception as exc:
+        err = "%s: %s" % (type(exc).__name__, str(exc)[:300])
+        reported = -1
+    if not ctl.all_ok(err is None):
+        return {"error": "RCCL communicator: %s" % ctl.allgather(err)}, None
+    counts = ctl.allgather(reported)
+
+    def sync_all():
+        jpegx.check(L.jpegx_stream_synchronize(s_comp), "sync")
+        jpegx.check(L.jpegx_stream_synchronize(s_comm), "sync")
+
+    def overlapped():
+        multigpu.transform_and_gather(comm, view, in_ptr, out_ptr, send_root, size, args.mode, args.param,
+                                      jpegx.F_PIXEL_INPUT, s_comp, s_comm, events, root=0, loopback=loopback)
+
+    def gather_only():
+        for k in range(view.rounds):
+            first, count = view.round_of(comm.rank, k)
+            sizes, offs = [0] * view.world, [0] * view.world
+            if comm.rank == 0:
+                for r in range(view.world):
+                    if r == 0 and not loopback:
+                        continue
+                    f, c = view.round_of(r, k)
+                    sizes[r], offs[r] = c * plane_out, f * plane_out
+            send = 0 if (comm.rank == 0 and not loopback) else count * plane_out
+            comm.gather_bytes(out_ptr + (first - lo) * plane_out, send, send_root, sizes, offs, root=0, stream=s_comm)
+
+    def timed(fn):
+        jpegx.check(L.jpegx_device_synchronize(), "sync")
+        ctl.barrier()
+        t0 = time.perf_counter()
+        fn()
+        sync_all()
+        t = time.perf_counter() - t0
+        return ctl.allreduce_max(t)
+
+    gather, e2e = None, None
+    try:
+        timed(overlapped)                                 # connection setup + warm-up (untimed)
+        t_e2e = timed(overlapped)
+        t_g = timed(gather_only)
+        into_root = sum((b - a) for a, b in spans[1:]) * plane_out if not loopback else planes * plane_out
+        # root-side check: what arrived for the first and the last plane of every other rank equals what
+        # the root's own GPU produces for those plane ids
+        ok = True
+        if rank == 0 or loopback:
+            scratch_in, scratch_out = jpegx.DeviceBuffer(size * size * 4), jpegx.DeviceBuffer(plane_out)
+            todo = [(lo, hi)] if loopback else spans[1:]
+            for a, b in todo:
+                for p in sorted({a, b - 1}):
+                    jpegx.generate_plane_device(scratch_in.ptr, size, size, args.kind, seed=0, plane=p)
+                    jpegx.forward_fused_device(scratch_in.ptr, size, size, scratch_out.ptr, args.mode, args.param, jpegx.F_PIXEL_INPUT)
+                    want = scratch_out.download((plane_out // 2,), np.int16)
+                    got = np.empty(plane_out // 2, np.int16)
+                    jpegx.check(L.jpegx_memcpy_d2h(got.ctypes.data, send_root + p * plane_out, got.nbytes, None), "d2h")
+                    jpegx.check(L.jpegx_device_synchronize(), "sync")
+                    ok = ok and bool(np.array_equal(got, want))
+            scratch_in.free()
+            scratch_out.free()
+        ok = bool(all(ctl.allgather(ok)))
+        gather = {"ms": round(t_g * 1e3, 3), "bytes_into_root": into_root, "GBps_into_root": round(into_root / t_g / 1e9, 2),
+                  "xgmi_bound_GBps": XGMI_ROOT_INGRESS_GBPS, "frac_of_xgmi_bound": round(into_root / t_g / 1e9 / XGMI_ROOT_INGRESS_GBPS, 4),
+                  "rccl_ranks_reported": counts, "chunk_planes": args.gather_chunk, "rounds": view.rounds, "root_copy_ok": ok,
+                  "transport": "loop-back rehearsal on one GPU (1-rank communicator per process)" if loopback else
+                               "jpegx_comm_gather_bytes: grouped ncclSend/ncclRecv of raw bytes, comm stream only, data already computed"}
+        e2e = {"ms": round(t_e2e * 1e3, 3), "Mblocks_per_s": round(total_blocks_per_step / t_e2e / 1e6, 2),
+               "what": "one pass: transform chunk k on the compute stream while chunk k-1 crosses xGMI on the comm stream "
+                       "(per-chunk events), until the whole batch's stream sits on rank 0; max over ranks"}
+    except Exception as exc:
+        gather = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
+    return gather, e2e
 
 
 if __name__ == "__main__":

@@ -18,6 +18,7 @@
 // variants, uint8 input, the one-wavefront-per-block comparison variant) and their C entry points.
 // Built with: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (explicit fma only).
 #include "jpegx_internal.h"
+#include <string.h>
 
 namespace {
 
@@ -25,21 +26,27 @@ namespace {
 // fused forward: DCT + quantise + zigzag.  VAR bit0 = PIXEL_INPUT, bit1 = DC exact.
 // BS = mean-pool factor of the fused SubSampling prologue (1 = none).
 // ------------------------------------------------------------------------------------------------
+template <int BS, int STAGED> struct PooledLds {
+    static constexpr int STAGE_BYTES = STAGED * 2 * BS * 1024;                 // staging buffer (0 if not staged)
+    static constexpr int FRONT = STAGE_BYTES > TILE_BYTES ? STAGE_BYTES : TILE_BYTES;
+    static constexpr int BYTES = FRONT + SCRATCH_DOUBLES * 8;
+};
+
+// body of one workgroup (= one wave = 64 blocks starting at block 64 * wg of this plane); `lds` is the
+// workgroup's PooledLds<BS, STAGED>::BYTES of shared memory
 template <int VAR, int BS, bool NT, int STAGED>
-__global__ __launch_bounds__(64) void k_forward_fused(const float *__restrict__ in, size_t pitch, int wb,
-                                                      int nblk, QuantParams prm, int16_t *__restrict__ out,
-                                                      unsigned long long *counters)
+__device__ __forceinline__ void forward_fused_body(unsigned char *lds, int wg, const float *__restrict__ in, size_t pitch, int wb,
+                                                   int nblk, const QuantParams &prm, int16_t *__restrict__ out,
+                                                   unsigned long long *counters)
 {
     constexpr bool PIXEL = (VAR & 1) != 0;
     constexpr bool DC_EXACT = (VAR & 2) != 0;
-    constexpr int STAGE_BYTES = STAGED * 2 * BS * 1024;                 // staging buffer (0 if not staged)
-    constexpr int FRONT = STAGE_BYTES > TILE_BYTES ? STAGE_BYTES : TILE_BYTES;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[FRONT + SCRATCH_DOUBLES * 8];
+    constexpr int FRONT = PooledLds<BS, STAGED>::FRONT;
     double *sA = reinterpret_cast<double *>(lds + FRONT);
     double *sM = sA + 64;
 
     const int lane = threadIdx.x;
-    const int g0 = blockIdx.x * 64;
+    const int g0 = wg * 64;
     const int g = g0 + lane;
     const bool valid = g < nblk;
     const int gc = valid ? g : nblk - 1;
@@ -202,6 +209,15 @@ __global__ __launch_bounds__(64) void k_forward_fused(const float *__restrict__ 
     store_tile<NT>(lds, out, g0, nblk, lane);
 }
 
+template <int VAR, int BS, bool NT, int STAGED>
+__global__ __launch_bounds__(64) void k_forward_fused(const float *__restrict__ in, size_t pitch, int wb,
+                                                      int nblk, QuantParams prm, int16_t *__restrict__ out,
+                                                      unsigned long long *counters)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char lds[PooledLds<BS, STAGED>::BYTES];
+    forward_fused_body<VAR, BS, NT, STAGED>(lds, blockIdx.x, in, pitch, wb, nblk, prm, out, counters);
+}
+
 // ------------------------------------------------------------------------------------------------
 // fused forward, LDS-staged input (the default kernel).  The wave's 64 blocks -- when W/8 is a
 // multiple of 64, one 8-row x 2 KiB strip of the plane -- are brought in by LDS-DMA
@@ -216,19 +232,18 @@ __global__ __launch_bounds__(64) void k_forward_fused(const float *__restrict__ 
 // After the compute the dead strip is reused as the output tile.
 // ------------------------------------------------------------------------------------------------
 template <int VAR, bool NT>
-__global__ __launch_bounds__(64) void k_forward_fused_strip(const float *__restrict__ in, size_t pitch, int wb,
-                                                            int nblk, QuantParams prm, int16_t *__restrict__ out,
-                                                            unsigned long long *counters)
+__device__ __forceinline__ void forward_strip_body(unsigned char *lds, int wg, const float *__restrict__ in, size_t pitch, int wb,
+                                                   int nblk, const QuantParams &prm, int16_t *__restrict__ out,
+                                                   unsigned long long *counters)
 {
     constexpr bool PIXEL = (VAR & 1) != 0;
     constexpr bool DC_EXACT = (VAR & 2) != 0;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[STRIP_LDS_BYTES];
     double *sA = reinterpret_cast<double *>(lds + STRIP_BYTES);
     double *sM = sA + 64;
     int16_t *sP = reinterpret_cast<int16_t *>(lds + STRIP_BYTES + SCRATCH_DOUBLES * 8);
 
     const int lane = threadIdx.x;
-    const int g0 = blockIdx.x * 64;
+    const int g0 = wg * 64;
     const bool valid = g0 + lane < nblk;
 
     // 16 DMA pieces of 1 KiB: piece (r, j) fills LDS bytes [r*2048 + j*1024, +1024); lane l of
@@ -307,6 +322,57 @@ __global__ __launch_bounds__(64) void k_forward_fused_strip(const float *__restr
         *reinterpret_cast<u32x4 *>(lds + tile_off(lane, c)) = u32x4{pk[c * 4 + 0], pk[c * 4 + 1], pk[c * 4 + 2], pk[c * 4 + 3]};
     __syncthreads();
     store_tile<NT>(lds, out, g0, nblk, lane);
+}
+
+template <int VAR, bool NT>
+__global__ __launch_bounds__(64) void k_forward_fused_strip(const float *__restrict__ in, size_t pitch, int wb,
+                                                            int nblk, QuantParams prm, int16_t *__restrict__ out,
+                                                            unsigned long long *counters)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char lds[STRIP_LDS_BYTES];
+    forward_strip_body<VAR, NT>(lds, blockIdx.x, in, pitch, wb, nblk, prm, out, counters);
+}
+
+// ------------------------------------------------------------------------------------------------
+// several planes in ONE grid (BASELINE.json configs[2]: Y + Cb + Cr of a 4:2:0 image).  One launch per
+// plane leaves the two 4096-workgroup chroma launches as a single generation of long-lived waves with
+// nothing to overlap their DMA phases with; as one grid the chroma workgroups are dispatched FIRST
+// (they live ~4x longer: 8 LDS-DMA phases) and the Y workgroups fill in behind them, so the chroma
+// tail overlaps the Y body.  Every workgroup finds its plane from the by-value descriptor table
+// (uniform scalar compare) and runs that plane's body: strip (bs = 1) or LDS-staged mean-pool (bs = 2, 4).
+// ------------------------------------------------------------------------------------------------
+constexpr int MAX_PLANES = JPEGX_MAX_PLANES;
+struct PlaneArgs {
+    const float *in;
+    int16_t *out;
+    size_t pitch;
+    int wb, nblk, bs;
+    int wg0;            // first workgroup of this plane in the grid
+};
+struct PlaneTable {
+    PlaneArgs p[MAX_PLANES];
+    int n;
+};
+
+template <int VAR, bool NT>
+__global__ __launch_bounds__(64) void k_forward_fused_planes(PlaneTable tab, QuantParams prm, unsigned long long *counters)
+{
+    constexpr int LDSB = STRIP_LDS_BYTES > PooledLds<4, 1>::BYTES ? STRIP_LDS_BYTES : PooledLds<4, 1>::BYTES;
+    static_assert(LDSB >= PooledLds<2, 2>::BYTES, "LDS budget");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[LDSB];
+    int i = 0;
+#pragma unroll
+    for (int k = 1; k < MAX_PLANES; ++k)
+        if (k < tab.n && (int)blockIdx.x >= tab.p[k].wg0) i = k;
+    i = __builtin_amdgcn_readfirstlane(i);
+    const PlaneArgs a = tab.p[i];     // uniform index into the kernarg segment: one scalar load
+    const int wg = (int)blockIdx.x - a.wg0;
+    if (a.bs == 1)
+        forward_strip_body<VAR, NT>(lds, wg, a.in, a.pitch, a.wb, a.nblk, prm, a.out, counters);
+    else if (a.bs == 2)
+        forward_fused_body<VAR, 2, NT, 2>(lds, wg, a.in, a.pitch, a.wb, a.nblk, prm, a.out, counters);
+    else
+        forward_fused_body<VAR, 4, NT, 1>(lds, wg, a.in, a.pitch, a.wb, a.nblk, prm, a.out, counters);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -765,6 +831,57 @@ int jpegx_forward_fused_pooled(const float *d_in, int H, int W, ptrdiff_t pitch,
     if (bs == 4) return launch_forward<4, false>(d_in, H, W, pitch, qp, flags, d_out, st);
     if (flags & JPEGX_F_TUNE_NO_NT) return launch_forward<1, false>(d_in, H, W, pitch, qp, flags, d_out, st);
     return launch_forward<1, true>(d_in, H, W, pitch, qp, flags, d_out, st);
+}
+
+int jpegx_forward_fused_planes(const jpegx_plane_desc *planes, int nplanes, int mode, double param, unsigned flags,
+                               jpegx_stream_t stream)
+{
+    if (!planes || nplanes < 1 || nplanes > MAX_PLANES) return fail(JPEGX_E_INVALID, "forward_planes: 1..JPEGX_MAX_PLANES plane descriptors");
+    QuantParams qp;
+    int rc = fill_forward_params(mode, param, &qp);
+    if (rc) return rc;
+    if (flags & JPEGX_F_TUNE_SKIP_EXACT) qp.tune |= 1;
+    // pooled planes first: their workgroups live longest, the bs = 1 workgroups fill in behind them
+    int order[MAX_PLANES], n = 0;
+    for (int pass = 0; pass < 3; ++pass)
+        for (int i = 0; i < nplanes; ++i) {
+            const int bs = planes[i].bs;
+            if (bs != 1 && bs != 2 && bs != 4) return fail(JPEGX_E_UNSUPPORTED, "fused mean-pool supports block_size 1, 2 and 4");
+            if ((pass == 0 && bs == 4) || (pass == 1 && bs == 2) || (pass == 2 && bs == 1)) order[n++] = i;
+        }
+    PlaneTable tab;
+    memset(&tab, 0, sizeof(tab));
+    long long wg = 0;
+    for (int k = 0; k < nplanes; ++k) {
+        const jpegx_plane_desc &d = planes[order[k]];
+        rc = check_plane(d.d_in, d.d_out, d.H, d.W, d.pitch / d.bs, 1);
+        if (rc) return rc;
+        if (d.pitch < (ptrdiff_t)d.W * d.bs || (d.pitch % 4) != 0 || !aligned16(d.d_in) || !aligned16(d.d_out))
+            return fail(JPEGX_E_INVALID, "forward_planes: pitch must be a multiple of 4 floats and >= W*bs; pointers 16-byte aligned");
+        PlaneArgs &a = tab.p[k];
+        a.in = d.d_in;
+        a.out = d.d_out;
+        a.pitch = (size_t)d.pitch;
+        a.wb = d.W / 8;
+        a.nblk = (d.H / 8) * a.wb;
+        a.bs = d.bs;
+        a.wg0 = (int)wg;
+        wg += (a.nblk + 63) / 64;
+        if (wg > 0x7FFFFFFFLL) return fail(JPEGX_E_INVALID, "forward_planes: more than 2^31 workgroups in one launch");
+    }
+    tab.n = nplanes;
+    const bool pixel = (flags & JPEGX_F_PIXEL_INPUT) != 0;
+    const bool dc_exact = pixel && is_pow2_float(qp.rq32[0]) && (qp.mode != JPEGX_Q_DIVIDE || (double)qp.rq32[0] * qp.param == 1.0);
+    const bool nt = !(flags & JPEGX_F_TUNE_NO_NT);
+    const dim3 grid((unsigned)wg), block(64);
+    hipStream_t st = (hipStream_t)stream;
+#define JPEGX_LP(VARV) \
+    do { if (nt) hipLaunchKernelGGL((k_forward_fused_planes<VARV, true>), grid, block, 0, st, tab, qp, g_counters); \
+         else hipLaunchKernelGGL((k_forward_fused_planes<VARV, false>), grid, block, 0, st, tab, qp, g_counters); } while (0)
+    if (dc_exact) JPEGX_LP(3); else if (pixel) JPEGX_LP(1); else JPEGX_LP(0);
+#undef JPEGX_LP
+    HIP_TRY(hipGetLastError());
+    return JPEGX_OK;
 }
 
 int jpegx_forward_fused(const float *d_in, int H, int W, ptrdiff_t pitch, int mode, double param, unsigned flags,

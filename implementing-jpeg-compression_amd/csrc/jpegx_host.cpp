@@ -106,6 +106,7 @@ typedef struct { char internal[128]; } rccl_unique_id;
 typedef int (*fn_get_unique_id)(rccl_unique_id *);
 typedef int (*fn_comm_init_rank)(void **, int, rccl_unique_id, int);
 typedef int (*fn_comm_destroy)(void *);
+typedef int (*fn_comm_count)(void *, int *);
 typedef int (*fn_send)(const void *, size_t, int, int, void *, void *);
 typedef int (*fn_recv)(void *, size_t, int, int, void *, void *);
 typedef int (*fn_group)(void);
@@ -116,6 +117,7 @@ struct Rccl {
     fn_get_unique_id get_unique_id = nullptr;
     fn_comm_init_rank comm_init_rank = nullptr;
     fn_comm_destroy comm_destroy = nullptr;
+    fn_comm_count comm_count = nullptr;
     fn_send send = nullptr;
     fn_recv recv = nullptr;
     fn_group group_start = nullptr, group_end = nullptr;
@@ -143,6 +145,7 @@ int load_rccl()
     r.get_unique_id = (fn_get_unique_id)dlsym(h, "ncclGetUniqueId");
     r.comm_init_rank = (fn_comm_init_rank)dlsym(h, "ncclCommInitRank");
     r.comm_destroy = (fn_comm_destroy)dlsym(h, "ncclCommDestroy");
+    r.comm_count = (fn_comm_count)dlsym(h, "ncclCommCount");
     r.send = (fn_send)dlsym(h, "ncclSend");
     r.recv = (fn_recv)dlsym(h, "ncclRecv");
     r.group_start = (fn_group)dlsym(h, "ncclGroupStart");
@@ -174,6 +177,8 @@ const int kNcclUint8 = 1;
 }  // namespace
 
 extern "C" {
+
+int jpegx_comm_available(void) { return load_rccl(); }
 
 int jpegx_comm_unique_id(void *id128)
 {
@@ -209,6 +214,18 @@ int jpegx_comm_destroy(jpegx_comm_t comm)
     int e = g_rccl.comm_destroy(c->nccl);
     delete c;
     return e ? rccl_fail("ncclCommDestroy", e) : JPEGX_OK;
+}
+
+int jpegx_comm_count(jpegx_comm_t comm, int *nranks)
+{
+    if (!comm || !nranks) return fail("null pointer");
+    Comm *c = static_cast<Comm *>(comm);
+    if (!g_rccl.comm_count) {
+        jpegx_internal_set_error("librccl.so lacks ncclCommCount");
+        return JPEGX_E_UNSUPPORTED;
+    }
+    int e = g_rccl.comm_count(c->nccl, nranks);      // what RCCL itself believes, not what we passed in
+    return e ? rccl_fail("ncclCommCount", e) : JPEGX_OK;
 }
 
 int jpegx_comm_gather_bytes(jpegx_comm_t comm, const void *d_send, size_t send_bytes, void *d_recv,

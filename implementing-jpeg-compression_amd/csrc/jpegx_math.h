@@ -24,7 +24,7 @@
 #include <stdint.h>
 #include <math.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define JPEGX_HD __host__ __device__ __forceinline__
 #else
 #define JPEGX_HD static inline __attribute__((always_inline))

@@ -116,6 +116,11 @@ int jpegx_event_record(jpegx_event_t event, jpegx_stream_t stream)
     HIP_TRY(hipEventRecord((hipEvent_t)event, (hipStream_t)stream));
     return JPEGX_OK;
 }
+int jpegx_stream_wait_event(jpegx_stream_t stream, jpegx_event_t event)
+{
+    HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)event, 0));
+    return JPEGX_OK;
+}
 int jpegx_event_synchronize(jpegx_event_t event) { HIP_TRY(hipEventSynchronize((hipEvent_t)event)); return JPEGX_OK; }
 int jpegx_event_elapsed_ms(jpegx_event_t start, jpegx_event_t stop, float *ms)
 {

@@ -64,11 +64,13 @@ SIGNATURES = {
     "jpegx_event_destroy": [_vp],
     "jpegx_event_record": [_vp, _vp],
     "jpegx_event_synchronize": [_vp],
+    "jpegx_stream_wait_event": [_vp, _vp],
     "jpegx_event_elapsed_ms": [_vp, _vp, _c.POINTER(_c.c_float)],
     "jpegx_generate_plane": [_vp, _int, _int, _pd, _int, _u32, _u32, _int, _vp],
     "jpegx_forward_fused": [_vp, _int, _int, _pd, _int, _dbl, _uint, _vp, _vp],
     "jpegx_forward_fused_pooled": [_vp, _int, _int, _pd, _int, _int, _dbl, _uint, _vp, _vp],
     "jpegx_forward_fused_u8": [_vp, _int, _int, _pd, _int, _int, _dbl, _uint, _vp, _vp],
+    "jpegx_forward_fused_planes": [_vp, _int, _int, _dbl, _uint, _vp],
     "jpegx_inverse_fused": [_vp, _int, _int, _int, _dbl, _uint, _vp, _pd, _int, _vp],
     "jpegx_inverse_fused_u8_inflated": [_vp, _int, _int, _int, _dbl, _uint, _int, _vp, _pd, _vp],
     "jpegx_dct8x8_f32": [_vp, _int, _int, _pd, _vp, _pd, _vp],
@@ -96,9 +98,11 @@ SIGNATURES = {
     "jpegx_entropy_emit": [_vp, _c.c_longlong, _vp, _vp, _vp],
     "jpegx_host_entropy_encode": [_vp, _c.c_longlong, _vp, _sz, _c.POINTER(_sz)],
     "jpegx_host_entropy_decode": [_vp, _sz, _c.c_longlong, _vp],
+    "jpegx_comm_available": [],
     "jpegx_comm_unique_id": [_vp],
     "jpegx_comm_create": [_c.POINTER(_vp), _int, _int, _vp],
     "jpegx_comm_destroy": [_vp],
+    "jpegx_comm_count": [_vp, _c.POINTER(_int)],
     "jpegx_comm_gather_bytes": [_vp, _vp, _sz, _vp, _c.POINTER(_sz), _c.POINTER(_sz), _int, _vp],
 }
 RESTYPES = {"jpegx_entropy_workspace_bytes": _sz}   # everything else returns int
@@ -231,6 +235,22 @@ def forward_fused_device(in_ptr, height, width, out_ptr, mode="qtable", param=0.
     """Enqueue steps 4+5+6 on device pointers (fp32 plane -> int16 zigzag stream)."""
     check(lib().jpegx_forward_fused_pooled(in_ptr, height, width, pitch or width * pool, pool, mode_of(mode),
                                            float(param), flags, out_ptr, stream), "jpegx_forward_fused")
+
+
+class PlaneDesc(ctypes.Structure):
+    """struct jpegx_plane_desc (include/jpegx.h)."""
+    _fields_ = [("d_in", _vp), ("d_out", _vp), ("H", _int), ("W", _int), ("pitch", _pd), ("bs", _int)]
+
+
+def forward_fused_planes_device(planes, mode="qtable", param=0.0, flags=F_PIXEL_INPUT, stream=None):
+    """Enqueue steps (1+)4+5+6 for several planes as ONE launch.  ``planes``: iterable of
+    (in_ptr, height, width, pitch_elems, block_size, out_ptr) with height/width AFTER pooling."""
+    planes = list(planes)
+    arr = (PlaneDesc * len(planes))()
+    for d, (in_ptr, h, w, pitch, bs, out_ptr) in zip(arr, planes):
+        d.d_in, d.d_out, d.H, d.W, d.pitch, d.bs = in_ptr, out_ptr, h, w, pitch, bs
+    check(lib().jpegx_forward_fused_planes(arr, len(planes), mode_of(mode), float(param), flags, stream),
+          "jpegx_forward_fused_planes")
 
 
 def forward_fused_u8_device(in_ptr, height, width, out_ptr, mode="qtable", param=0.0, flags=0, pitch=None,

@@ -1,15 +1,38 @@
-"""Sharding of the block-transform path over the GPUs of one node.
+"""Sharding of the block-transform path over the GPUs of one node -- no PyTorch.
 
 Blocks -- and therefore planes and block rows -- are independent units (no DC prediction, no
-inter-block state anywhere in steps 4-6; pipeline/__init__.py:104-106 processes bands one after
-another with nothing shared), so the data path needs NO collective: every rank transforms its
-own contiguous range.  The only exchange is the final gather of the int16 coefficient stream to
-one rank, done with ``torch.distributed`` (backend "nccl" = RCCL over xGMI on the GPUs, "gloo"
-in the CPU tests).  torch is plumbing here (process group + device tensors); the kernels are
-reached through libjpegx as everywhere else.
+inter-block state anywhere in steps 4-6; the reference's pipeline/__init__.py:104-106 processes
+bands one after another with nothing shared), so the data path needs NO collective: every rank
+transforms its own contiguous range.  The only exchange is the final gather of the int16
+coefficient stream to one rank over RCCL/xGMI.
+
+Pieces (one process per GPU):
+  * ``shard_*``          contiguous unit ranges per rank;
+  * ``launch_ranks``     start N copies of a script with the RANK / LOCAL_RANK / WORLD_SIZE /
+                         MASTER_* environment ``torch.distributed.run`` would give them (so a
+                         script works the same under either launcher);
+  * ``ControlPlane``     the small-message side channel between the ranks (TCP on 127.0.0.1:
+                         barrier, all-gather / max / min of scalars, broadcast of the 128-byte
+                         RCCL id).  Bulk data never goes through it;
+  * ``NativeComm``       the RCCL communicator owned by libjpegx (``jpegx_comm_*``);
+  * ``transform_and_gather``  the multi-GPU driver step: forward transform of the rank's
+                         planes chunk by chunk on one HIP stream while a second stream ships every
+                         finished chunk to the root (grouped ncclSend/ncclRecv), i.e. the gather
+                         is overlapped with the compute.
 """
+import base64
+import json
+import os
+import socket
+import struct
+import subprocess
+import sys
+import time
 
 
+# ---------------------------------------------------------------------------------------------
+# shard planning
+# ---------------------------------------------------------------------------------------------
 def shard_range(n_units, world, rank):
     """Contiguous [lo, hi) of ``n_units`` for ``rank``: sizes differ by at most one, low ranks first."""
     if world <= 0 or not 0 <= rank < world:
@@ -33,39 +56,250 @@ def shard_block_rows(height, world, rank):
     return lo * 8, hi * 8
 
 
-def gather_stream(local, dst=0, group=None):
-    """Gather every rank's coefficient stream (a 1-D/N-D tensor, sizes may differ) on ``dst``.
+def chunk_spans(n_units, chunk):
+    """[lo, hi) spans of at most ``chunk`` units covering 0..n_units."""
+    chunk = max(1, int(chunk))
+    return [(lo, min(n_units, lo + chunk)) for lo in range(0, n_units, chunk)]
 
-    Returns the list of per-rank tensors on ``dst`` (in rank order, so concatenating them yields the
-    stream of the un-sharded job) and None elsewhere.  One size all-gather + one data gather.
+
+# ---------------------------------------------------------------------------------------------
+# process launcher
+# ---------------------------------------------------------------------------------------------
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(nranks, argv, extra_env=None, poll_s=0.05, grace_s=10.0):
+    """Run ``python argv...`` once per rank and return the job's exit code (0 iff every rank
+    returned 0).  Must be called before the calling process has touched the GPU.  When a rank
+    fails the others are given ``grace_s`` seconds and are then terminated by PID."""
+    port = _free_port()
+    procs = []
+    for r in range(nranks):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(nranks),
+                    "LOCAL_WORLD_SIZE": str(nranks), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port),
+                    "JPEGX_LAUNCHER": "jpegx.multigpu.launch_ranks"})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL peer-to-peer needs it here
+        if extra_env:
+            env.update(extra_env)
+        procs.append(subprocess.Popen([sys.executable] + list(argv), env=env))
+    rc, failed_at = 0, None
+    while True:
+        alive = 0
+        for p in procs:
+            code = p.poll()
+            if code is None:
+                alive += 1
+            elif code != 0 and rc == 0:
+                rc, failed_at = code, time.monotonic()
+        if alive == 0:
+            return rc
+        if failed_at is not None and time.monotonic() - failed_at > grace_s:
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            for p in procs:
+                try:
+                    p.wait(timeout=5)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            return rc
+        time.sleep(poll_s)
+
+
+def rank_env():
+    """(rank, local_rank, world) from the launcher's environment (1 process: 0, 0, 1)."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+# ---------------------------------------------------------------------------------------------
+# control plane
+# ---------------------------------------------------------------------------------------------
+class ControlPlaneError(RuntimeError):
+    pass
+
+
+class ControlPlane:
+    """Star of TCP connections on 127.0.0.1 with rank 0 in the centre; JSON messages.
+
+    Rendezvous: rank 0 listens on an ephemeral port and publishes it in a file named after
+    MASTER_PORT (``torch.distributed.run`` keeps MASTER_PORT itself busy with its own store, so it
+    cannot be bound here); the other ranks poll the file, connect and say who they are.  A stale
+    file (an earlier job on the same MASTER_PORT) points at a dead or foreign port: the hello is
+    refused and the rank polls again.  Every socket operation has a timeout, so a rank that died
+    turns into an exception on the others instead of a hang.
     """
-    import torch
-    import torch.distributed as dist
-    world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
-    dtype = local.dtype
-    # ship raw bytes: neither RCCL/NCCL nor gloo has an int16 datatype
-    flat = local.contiguous().reshape(-1).view(torch.uint8)
-    sizes = torch.zeros(world, dtype=torch.int64, device=flat.device)
-    sizes[rank] = flat.numel()
-    dist.all_reduce(sizes, group=group)
-    sizes = [int(s) for s in sizes.tolist()]
-    cap = max(sizes)
-    if flat.numel() < cap:                                  # gather wants equal shapes: pad the short ones
-        flat = torch.cat([flat, flat.new_zeros(cap - flat.numel())])
-    bufs = [torch.empty(cap, dtype=flat.dtype, device=flat.device) for _ in range(world)] if rank == dst else None
-    dist.gather(flat, bufs, dst=dst, group=group)
-    if rank != dst:
-        return None
-    return [b[:n].view(dtype) for b, n in zip(bufs, sizes)]
+    MAGIC = "jpegx-ctl-1"
+
+    def __init__(self, rank=None, world=None, key=None, timeout=900.0, connect_timeout=180.0):
+        env_rank, _, env_world = rank_env()
+        self.rank = env_rank if rank is None else int(rank)
+        self.world = env_world if world is None else int(world)
+        self.timeout = float(timeout)
+        self._peers = {}          # rank 0: rank -> socket
+        self._up = None           # others: socket to rank 0
+        self._path = None
+        if self.world <= 1:
+            return
+        if key is None:
+            key = "%s_%s" % (os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "none"))
+        self.key = "".join(c if c.isalnum() or c in "._-" else "_" for c in str(key))
+        base = os.environ.get("JPEGX_CTL_DIR") or "/tmp"
+        self._path = os.path.join(base, "jpegx_ctl_%d_%s" % (os.getuid(), self.key))
+        if self.rank == 0:
+            self._serve(connect_timeout)
+        else:
+            self._join(connect_timeout)
+
+    # -- wire format: 4-byte big-endian length + UTF-8 JSON -----------------------------------
+    @staticmethod
+    def _send(sock, obj):
+        data = json.dumps(obj).encode()
+        sock.sendall(struct.pack(">I", len(data)) + data)
+
+    @staticmethod
+    def _recv(sock):
+        def exactly(n):
+            buf = b""
+            while len(buf) < n:
+                part = sock.recv(n - len(buf))
+                if not part:
+                    raise ControlPlaneError("control-plane peer closed the connection")
+                buf += part
+            return buf
+        (n,) = struct.unpack(">I", exactly(4))
+        return json.loads(exactly(n).decode())
+
+    def _serve(self, connect_timeout):
+        srv = socket.socket()
+        srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+        srv.bind(("127.0.0.1", 0))
+        srv.listen(self.world)
+        port = srv.getsockname()[1]
+        tmp = "%s.%d.tmp" % (self._path, os.getpid())
+        with open(tmp, "w") as f:
+            f.write("%d %d\n" % (port, os.getpid()))
+        os.replace(tmp, self._path)                        # atomic publish (replaces a stale file)
+        deadline = time.monotonic() + connect_timeout
+        try:
+            while len(self._peers) < self.world - 1:
+                srv.settimeout(max(0.1, deadline - time.monotonic()))
+                try:
+                    conn, _ = srv.accept()
+                except socket.timeout:
+                    raise ControlPlaneError("only %d of %d ranks joined the control plane within %.0f s"
+                                            % (len(self._peers) + 1, self.world, connect_timeout))
+                conn.settimeout(10.0)
+                try:
+                    hello = self._recv(conn)
+                except Exception:
+                    conn.close()
+                    continue
+                ok = (isinstance(hello, dict) and hello.get("magic") == self.MAGIC and hello.get("key") == self.key
+                      and hello.get("world") == self.world and isinstance(hello.get("rank"), int)
+                      and 0 < hello["rank"] < self.world and hello["rank"] not in self._peers)
+                self._send(conn, {"ok": bool(ok)})
+                if not ok:
+                    conn.close()
+                    continue
+                conn.settimeout(self.timeout)
+                conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                self._peers[hello["rank"]] = conn
+        finally:
+            srv.close()
+
+    def _join(self, connect_timeout):
+        deadline = time.monotonic() + connect_timeout
+        last = "no rendezvous file %s" % self._path
+        while time.monotonic() < deadline:
+            try:
+                with open(self._path) as f:
+                    port = int(f.read().split()[0])
+                s = socket.create_connection(("127.0.0.1", port), timeout=5.0)
+                try:
+                    s.settimeout(10.0)
+                    self._send(s, {"magic": self.MAGIC, "key": self.key, "world": self.world, "rank": self.rank})
+                    if self._recv(s).get("ok"):
+                        s.settimeout(self.timeout)
+                        s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                        self._up = s
+                        return
+                    last = "hello refused by the process on port %d" % port
+                except Exception as exc:
+                    last = "%s: %s" % (type(exc).__name__, exc)
+                s.close()
+            except (OSError, ValueError, IndexError) as exc:
+                last = "%s: %s" % (type(exc).__name__, exc)
+            time.sleep(0.05)
+        raise ControlPlaneError("rank %d could not join the control plane: %s" % (self.rank, last))
+
+    # -- collectives on small JSON-serialisable values ---------------------------------------
+    def allgather(self, value):
+        """Every rank's ``value`` as a list in rank order, on every rank."""
+        if self.world <= 1:
+            return [value]
+        try:
+            if self.rank == 0:
+                vals = [value] + [self._recv(self._peers[r]) for r in range(1, self.world)]
+                for r in range(1, self.world):
+                    self._send(self._peers[r], vals)
+                return vals
+            self._send(self._up, value)
+            return self._recv(self._up)
+        except (OSError, ValueError) as exc:
+            raise ControlPlaneError("control-plane exchange failed on rank %d: %s: %s"
+                                    % (self.rank, type(exc).__name__, exc))
+
+    def barrier(self):
+        self.allgather(None)
+
+    def allreduce_max(self, x):
+        return max(self.allgather(x))
+
+    def allreduce_min(self, x):
+        return min(self.allgather(x))
+
+    def all_ok(self, ok):
+        """True iff ``ok`` on every rank: taken BEFORE entering an RCCL call so that a rank-local
+        failure makes every rank skip the collective instead of leaving the others blocked in it."""
+        return all(bool(v) for v in self.allgather(bool(ok)))
+
+    def bcast_bytes(self, data, src=0):
+        enc = base64.b64encode(data).decode() if self.rank == src and data is not None else None
+        return base64.b64decode(self.allgather(enc)[src])
+
+    def close(self):
+        for s in list(self._peers.values()) + ([self._up] if self._up else []):
+            try:
+                s.close()
+            except OSError:
+                pass
+        self._peers, self._up = {}, None
+        if self.rank == 0 and self._path:
+            try:
+                os.unlink(self._path)
+            except OSError:
+                pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
 
 
+# ---------------------------------------------------------------------------------------------
+# RCCL communicator (libjpegx jpegx_comm_*)
+# ---------------------------------------------------------------------------------------------
 class NativeComm:
-    """RCCL communicator owned by libjpegx (jpegx_comm_*): the PyTorch-free form of the gather.
+    """RCCL communicator owned by libjpegx on the calling thread's current device.
 
-    ``exchange_id`` is any callable that takes rank 0's 128-byte id (bytes on rank 0, None elsewhere)
-    and returns the id on every rank -- e.g. an MPI bcast, a shared file, or
-    ``NativeComm.exchange_via_torch`` when a torch.distributed group (gloo is enough) exists.
+    ``exchange_id`` takes rank 0's 128-byte id (bytes on rank 0, None elsewhere) and returns it on
+    every rank -- ``ControlPlane.bcast_bytes`` here; an MPI bcast or a shared file would do too.
     """
 
     def __init__(self, nranks, rank, exchange_id):
@@ -83,16 +317,17 @@ class NativeComm:
         jpegx.check(L.jpegx_comm_create(ctypes.byref(handle), nranks, rank, ident), "jpegx_comm_create")
         self.handle, self.nranks, self.rank = handle.value, nranks, rank
 
-    @staticmethod
-    def exchange_via_torch(ident):
-        import torch.distributed as dist
-        box = [ident]
-        dist.broadcast_object_list(box, src=0)
-        return box[0]
+    def count(self):
+        """Number of ranks RCCL itself reports for this communicator (ncclCommCount)."""
+        import ctypes
+        n = ctypes.c_int(0)
+        self._jpegx.check(self._jpegx.lib().jpegx_comm_count(self.handle, ctypes.byref(n)), "jpegx_comm_count")
+        return n.value
 
-    def gather_bytes(self, send_ptr, send_bytes, recv_ptr=None, recv_bytes=None, root=0, stream=None):
-        """Every rank sends ``send_bytes`` from ``send_ptr``; the root lays rank r's bytes out at the
-        running offset of ``recv_bytes`` inside ``recv_ptr``.  Enqueues on ``stream``."""
+    def gather_bytes(self, send_ptr, send_bytes, recv_ptr=None, recv_bytes=None, recv_offsets=None, root=0, stream=None):
+        """Every rank sends ``send_bytes`` from ``send_ptr`` (0 = nothing to send); the root receives
+        ``recv_bytes[r]`` bytes from rank r at ``recv_ptr + recv_offsets[r]`` (default: running
+        offsets).  Enqueues on ``stream``; nothing is synchronised."""
         import ctypes
         n = self.nranks
         sizes = (ctypes.c_size_t * n)(*([0] * n))
@@ -100,7 +335,8 @@ class NativeComm:
         if self.rank == root:
             run = 0
             for r in range(n):
-                sizes[r], offs[r] = int(recv_bytes[r]), run
+                sizes[r] = int(recv_bytes[r])
+                offs[r] = int(recv_offsets[r]) if recv_offsets is not None else run
                 run += int(recv_bytes[r])
         self._jpegx.check(self._jpegx.lib().jpegx_comm_gather_bytes(self.handle, send_ptr, int(send_bytes), recv_ptr, sizes, offs,
                                                                       root, stream), "jpegx_comm_gather_bytes")
@@ -109,3 +345,60 @@ class NativeComm:
         if self.handle:
             self._jpegx.lib().jpegx_comm_destroy(self.handle)
             self.handle = None
+
+
+# ---------------------------------------------------------------------------------------------
+# the multi-GPU driver step
+# ---------------------------------------------------------------------------------------------
+class GatherPlan:
+    """Where every rank's planes sit in the root's stream: plane p of the batch at byte
+    ``p * plane_stream_bytes`` -- concatenating the ranks in order IS the un-sharded stream."""
+
+    def __init__(self, n_planes, world, plane_stream_bytes, chunk_planes):
+        self.world, self.plane_bytes = int(world), int(plane_stream_bytes)
+        self.spans = [shard_planes(n_planes, world, r) for r in range(world)]
+        self.chunk = max(1, int(chunk_planes))
+        self.rounds = max((hi - lo + self.chunk - 1) // self.chunk for lo, hi in self.spans) if n_planes else 0
+
+    def round_of(self, rank, k):
+        """(first plane, count) that ``rank`` ships in round k (count 0 when it has run out)."""
+        lo, hi = self.spans[rank]
+        a = min(hi, lo + k * self.chunk)
+        return a, min(hi, a + self.chunk) - a
+
+
+def transform_and_gather(comm, plan, in_ptr, stream_ptr, root_ptr, size, mode, param, flags, compute_stream, comm_stream,
+                         events, root=0, loopback=False):
+    """Forward-transform the rank's planes (``size`` x ``size`` fp32 each, stacked at ``in_ptr``) in
+    chunks of ``plan.chunk`` planes on ``compute_stream``; after each chunk an event releases
+    ``comm_stream``, which ships the chunk's int16 stream to the root with one grouped
+    ncclSend/ncclRecv round (``comm.gather_bytes``).  The root's own planes are written straight
+    into its slot of the gathered stream (``root_ptr``), so nothing is copied for them.
+    ``stream_ptr``: where this rank's stream starts (on the root: root_ptr + its plane offset).
+    ``loopback`` (single-GPU rehearsal of the control flow with a 1-rank communicator): the rank
+    also ships its own chunks to itself through RCCL, into ``root_ptr``, which must then be a
+    buffer distinct from ``stream_ptr``.  Enqueue-only; the caller synchronises both streams."""
+    import jpegx
+    L = jpegx.lib()
+    rank = comm.rank
+    lo_mine = plan.spans[rank][0]
+    in_plane, out_plane = size * size * 4, plan.plane_bytes
+    for k in range(plan.rounds):
+        first, count = plan.round_of(rank, k)
+        if count:
+            off = first - lo_mine
+            jpegx.forward_fused_device(in_ptr + off * in_plane, size * count, size, stream_ptr + off * out_plane,
+                                       mode, param, flags, stream=compute_stream)
+        jpegx.check(L.jpegx_event_record(events[k].handle, compute_stream), "jpegx_event_record")
+        jpegx.check(L.jpegx_stream_wait_event(comm_stream, events[k].handle), "jpegx_stream_wait_event")
+        sizes = [0] * plan.world
+        offs = [0] * plan.world
+        if rank == root:
+            for r in range(plan.world):
+                if r == root and not loopback:
+                    continue                       # own planes are already in place
+                f, c = plan.round_of(r, k)
+                sizes[r], offs[r] = c * out_plane, f * out_plane
+        send = 0 if (rank == root and not loopback) else count * out_plane
+        comm.gather_bytes(stream_ptr + (first - lo_mine) * out_plane, send, root_ptr, sizes, offs, root=root,
+                          stream=comm_stream)

@@ -103,6 +103,9 @@ int jpegx_event_create(jpegx_event_t *event);
 int jpegx_event_destroy(jpegx_event_t event);
 int jpegx_event_record(jpegx_event_t event, jpegx_stream_t stream);
 int jpegx_event_synchronize(jpegx_event_t event);
+/* make later work on `stream` wait for `event` (hipStreamWaitEvent): orders the gather stream behind
+ * the transform stream chunk by chunk (jpegx.multigpu.transform_and_gather) */
+int jpegx_stream_wait_event(jpegx_stream_t stream, jpegx_event_t event);
 int jpegx_event_elapsed_ms(jpegx_event_t start, jpegx_event_t stop, float *ms);
 
 /* ---- synthetic planes (no reference counterpart; stands in for util.band_to_array,
@@ -123,6 +126,21 @@ int jpegx_forward_fused(const float *d_in, int H, int W, ptrdiff_t pitch, int mo
  * input plane is [H*bs][W*bs] and is averaged over bs x bs tiles (bs in {1,2,4}) on load.    */
 int jpegx_forward_fused_pooled(const float *d_in, int H, int W, ptrdiff_t pitch, int bs, int mode,
                                double param, unsigned flags, int16_t *d_out, jpegx_stream_t stream);
+
+/* Several planes in ONE launch (BASELINE.json configs[2]: the Y, Cb and Cr bands that
+ * pipeline/__init__.py:104-106 compresses one after another): every descriptor is one
+ * jpegx_forward_fused_pooled job; the pooled planes' workgroups are dispatched first and the
+ * bs = 1 planes fill in behind them.  Same quantiser and flags for all planes.               */
+#define JPEGX_MAX_PLANES 8
+typedef struct jpegx_plane_desc {
+    const float *d_in; /* fp32 plane [H*bs][pitch]                          */
+    int16_t *d_out;    /* this plane's zigzag stream [H/8][W/8][64]         */
+    int H, W;          /* size AFTER pooling, multiples of 8                */
+    ptrdiff_t pitch;   /* elements between input rows (>= W*bs)             */
+    int bs;            /* SubSampling factor fused on load: 1, 2 or 4       */
+} jpegx_plane_desc;
+int jpegx_forward_fused_planes(const jpegx_plane_desc *planes, int nplanes, int mode, double param,
+                               unsigned flags, jpegx_stream_t stream);
 
 /* The same on uint8 planes -- the form in which image bands arrive (util.band_to_array,
  * util.py:110-112): d_in is [H*bs][pitch] bytes, bs in {1,2,4} (bs > 1 fuses the bs x bs mean of
@@ -203,9 +221,11 @@ int jpegx_host_entropy_decode(const uint8_t *h_bytes, size_t nbytes, long long n
  *   jpegx_comm_gather_bytes(...): every rank sends send_bytes; the root receives recv_bytes[r] bytes
  *   from rank r at d_recv + recv_offsets[r].  Enqueued on `stream`.                              */
 typedef void *jpegx_comm_t;
+int jpegx_comm_available(void); /* 0 iff librccl could be bound (no communicator is created) */
 int jpegx_comm_unique_id(void *id128);
 int jpegx_comm_create(jpegx_comm_t *comm, int nranks, int rank, const void *id128);
 int jpegx_comm_destroy(jpegx_comm_t comm);
+int jpegx_comm_count(jpegx_comm_t comm, int *nranks); /* ncclCommCount: the size RCCL reports */
 int jpegx_comm_gather_bytes(jpegx_comm_t comm, const void *d_send, size_t send_bytes, void *d_recv,
                             const size_t *recv_bytes, const size_t *recv_offsets, int root,
                             jpegx_stream_t stream);

@@ -1,5 +1,7 @@
 """GPU parity (MI355X): every kernel of libjpegx.so, through the C ABI, against the oracle and
 against the golden vectors produced by the unmodified reference (tests/golden/make_golden.py)."""
+import ctypes
+
 import numpy as np
 import pytest
 
@@ -319,6 +321,82 @@ def test_native_rccl_gather_single_rank(gpu):
         assert np.array_equal(dst.download(zz.shape, np.int16), zz)
     finally:
         comm.close()
+
+
+def test_overlapped_transform_and_gather_loopback(gpu):
+    """The multi-GPU driver step (jpegx.multigpu.transform_and_gather) on one GPU: chunked transform on
+    one stream, per-chunk events, send/recv of every chunk on a second stream through a 1-rank RCCL
+    communicator; what lands in the root buffer is the oracle's stream of every plane, and RCCL
+    reports the communicator size it was created with."""
+    from jpegx import multigpu
+    n, planes, chunk = 256, 5, 2
+    L = gpu.lib()
+    src, out, root = gpu.DeviceBuffer(planes * n * n * 4), gpu.DeviceBuffer(planes * n * n * 2), gpu.DeviceBuffer(planes * n * n * 2)
+    for p in range(planes):
+        gpu.generate_plane_device(src.ptr + p * n * n * 4, n, n, "noise", seed=9, plane=p)
+    gpu.check(L.jpegx_memset(root.ptr, 0, planes * n * n * 2, None))
+    gpu.check(L.jpegx_device_synchronize())
+    s1, s2 = ctypes.c_void_p(), ctypes.c_void_p()
+    gpu.check(L.jpegx_stream_create(ctypes.byref(s1)))
+    gpu.check(L.jpegx_stream_create(ctypes.byref(s2)))
+    plan = multigpu.GatherPlan(planes, 1, n * n * 2, chunk)
+    events = [gpu.Event() for _ in range(plan.rounds)]
+    comm = multigpu.NativeComm(1, 0, lambda ident: ident)
+    try:
+        assert comm.count() == 1
+        multigpu.transform_and_gather(comm, plan, src.ptr, out.ptr, root.ptr, n, "qtable", 0.0, gpu.F_PIXEL_INPUT,
+                                      s1.value, s2.value, events, root=0, loopback=True)
+        gpu.check(L.jpegx_stream_synchronize(s1.value))
+        gpu.check(L.jpegx_stream_synchronize(s2.value))
+        got = root.download((planes, n // 8, n // 8, 64), np.int16)
+        for p in range(planes):
+            assert np.array_equal(got[p], oracle.forward_f32(gpu.synth.generate_plane("noise", n, n, seed=9, plane=p), "qtable"))
+    finally:
+        comm.close()
+        gpu.check(L.jpegx_stream_destroy(s1.value))
+        gpu.check(L.jpegx_stream_destroy(s2.value))
+
+
+@pytest.mark.parametrize("kind", ["noise", "smooth"])
+def test_planes_in_one_launch_match_the_oracle(gpu, kind):
+    """jpegx_forward_fused_planes (configs[2] layout, reduced size): a bs = 1 plane, two 2x2-pooled planes and
+    a 4x4-pooled ragged plane in ONE grid give each plane's oracle stream; descriptor order is free."""
+    n = 512
+    specs = [(n, n, 1), (n // 2, n // 2, 2), (n // 2, n // 2, 2), (40, 72, 4)]     # (H, W after pooling, bs)
+    bufs, outs, want, descs = [], [], [], []
+    for i, (h, w, bs) in enumerate(specs):
+        full = gpu.synth.generate_plane(kind, h * bs, w * bs, seed=21, plane=i)
+        b, o = gpu.DeviceBuffer(full.nbytes), gpu.DeviceBuffer(h * w * 2)
+        b.upload(full)
+        bufs.append(b)
+        outs.append(o)
+        pooled = full if bs == 1 else oracle.mean_pool(full.astype(np.float64), bs)
+        want.append(oracle.forward_f32(pooled, "qtable"))
+        descs.append((b.ptr, h, w, w * bs, bs, o.ptr))
+    for order in ([0, 1, 2, 3], [3, 1, 0, 2]):
+        for o, (h, w, bs) in zip(outs, specs):
+            gpu.check(gpu.lib().jpegx_memset(o.ptr, 0xFF, h * w * 2, None))
+        gpu.forward_fused_planes_device([descs[i] for i in order], "qtable", 0.0, gpu.F_PIXEL_INPUT)
+        gpu.check(gpu.lib().jpegx_device_synchronize())
+        for o, w_, (h, w, bs) in zip(outs, want, specs):
+            assert np.array_equal(o.download((h // 8, w // 8, 64), np.int16), w_), (order, h, w, bs)
+    with pytest.raises(gpu.JpegxError):
+        gpu.forward_fused_planes_device([descs[0]] * 9)
+    with pytest.raises(gpu.JpegxError):
+        gpu.forward_fused_planes_device([(bufs[0].ptr, n, n, n, 3, outs[0].ptr)])
+
+
+@pytest.mark.parametrize("kind", ["noise", "smooth"])
+def test_inverse_fused_full_size_vs_oracle(gpu, kind):
+    """configs[3] at full size: the fused inverse of a whole 4096x4096 plane (f32, clamped, and int16)
+    equals the oracle's reconstruction sample for sample."""
+    n = 4096
+    a = gpu.synth.generate_plane(kind, n, n, seed=13)
+    zz = gpu.forward_fused(a, "qtable")
+    want = oracle.inverse_i16(zz, "qtable")
+    assert np.array_equal(gpu.inverse_fused(zz, "qtable", out="i16").astype(np.int32), want)
+    got = gpu.inverse_fused(zz, "qtable", out="f32", clamp=True)
+    assert np.array_equal(got, np.clip(want, 0, 255).astype(np.float32))
 
 
 def test_unusual_quantiser_parameters(gpu):

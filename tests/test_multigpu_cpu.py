@@ -1,7 +1,9 @@
-"""Multi-GPU path on the CPU: world_size-2 gloo run of the sharding + gather logic
-(jpegx/multigpu.py).  The per-rank transform is stood in for by the oracle (no GPU here); what is
-under test is that contiguous plane / block-row shards plus the rank-ordered gather reproduce the
-un-sharded coefficient stream exactly."""
+"""Multi-GPU path on the CPU (no GPU here): shard planning, the rank launcher, the TCP control
+plane and bench.py's N > 1 control flow (``--dry-run``) -- started bare (own launcher) and under
+``torch.distributed.run`` the way the driver starts it.  A world_size-2 gloo run checks that
+contiguous plane / block-row shards plus a rank-ordered gather reproduce the un-sharded
+coefficient stream exactly (the per-rank transform is stood in for by the oracle)."""
+import json
 import os
 import socket
 import subprocess
@@ -29,7 +31,117 @@ def test_shard_ranges_cover_everything_once():
         shard_range(4, 2, 2)
 
 
-WORKER = r'''
+def test_gather_plan_places_every_plane_exactly_once():
+    """Every plane of the batch is shipped in exactly one round by exactly its owner, at its own
+    offset of the root's stream; ranks that run out early send nothing (uneven shards)."""
+    from jpegx.multigpu import GatherPlan
+    for n, world, chunk in ((1024, 8, 4), (10, 3, 4), (5, 2, 1), (7, 8, 2), (16, 1, 3)):
+        plan = GatherPlan(n, world, 100, chunk)
+        seen = []
+        for k in range(plan.rounds):
+            for r in range(world):
+                first, count = plan.round_of(r, k)
+                assert 0 <= count <= chunk
+                lo, hi = plan.spans[r]
+                assert count == 0 or (lo <= first and first + count <= hi)
+                seen.extend(range(first, first + count))
+        assert sorted(seen) == list(range(n))
+        for r in range(world):
+            assert plan.round_of(r, plan.rounds)[1] == 0
+
+
+CTL_WORKER = r'''
+import os, sys
+sys.path.insert(0, %(pkg)r)
+from jpegx.multigpu import ControlPlane, rank_env
+rank, local_rank, world = rank_env()
+with ControlPlane() as ctl:
+    assert ctl.allgather({"r": rank, "pid": os.getpid()})[rank]["r"] == rank
+    assert [v["r"] for v in ctl.allgather({"r": rank})] == list(range(world))
+    assert ctl.allreduce_max(float(rank)) == float(world - 1)
+    assert ctl.allreduce_min(float(rank)) == 0.0
+    ident = ctl.bcast_bytes(bytes(range(128)) if rank == 0 else None)
+    assert ident == bytes(range(128))
+    assert ctl.all_ok(True) is True
+    assert ctl.all_ok(rank != world - 1) is False          # one failing rank is seen by everybody
+    for _ in range(50):
+        ctl.barrier()
+if "--fail-rank" in sys.argv and rank == int(sys.argv[sys.argv.index("--fail-rank") + 1]):
+    sys.exit(3)
+'''
+
+
+def _write(tmp_path, name, text):
+    path = tmp_path / name
+    path.write_text(text % {"repo": REPO, "pkg": PKG})
+    return str(path)
+
+
+def test_own_launcher_and_control_plane(tmp_path):
+    from jpegx.multigpu import launch_ranks
+    script = _write(tmp_path, "ctl_worker.py", CTL_WORKER)
+    env = {"JPEGX_CTL_DIR": str(tmp_path)}
+    assert launch_ranks(3, [script], extra_env=env) == 0
+    assert launch_ranks(2, [script, "--fail-rank", "1"], extra_env=env) == 3      # a failing rank fails the job
+    assert not [f for f in os.listdir(tmp_path) if f.startswith("jpegx_ctl_")]     # rendezvous files are removed
+
+
+def test_control_plane_ignores_a_stale_rendezvous_file(tmp_path):
+    """A file left behind by an earlier job on the same MASTER_PORT points at a dead port: the ranks
+    keep polling until the live rank 0 has replaced it."""
+    from jpegx.multigpu import launch_ranks
+    script = _write(tmp_path, "ctl_worker.py", CTL_WORKER)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        dead = s.getsockname()[1]
+    port = 29876
+    stale = tmp_path / ("jpegx_ctl_%d_%d_none" % (os.getuid(), port))
+    stale.write_text("%d 1\n" % dead)
+    # launch_ranks picks its own MASTER_PORT; force the key so that the stale file is the one consulted
+    code = "import sys; sys.path.insert(0, %r)\nfrom jpegx.multigpu import launch_ranks\n" \
+           "import jpegx.multigpu as m\nm._free_port = lambda: %d\n" \
+           "sys.exit(launch_ranks(2, [%r], extra_env={'JPEGX_CTL_DIR': %r}))\n" % (PKG, port, script, str(tmp_path))
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _bench_line(res):
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    return json.loads(lines[0])
+
+
+def test_bench_launches_itself_for_n_ranks(tmp_path):
+    """`python bench.py --gpus 2` with nothing around it: it must start its own two ranks."""
+    env = dict(os.environ, JPEGX_CTL_DIR=str(tmp_path))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--dry-run", "--planes-total", "5"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    line = _bench_line(res)
+    assert line["dry_run"] and line["n_gpus"] == 2 and line["all_ok"] is True
+    assert line["shards"] == [[0, 3], [3, 5]] and line["launcher"] == "jpegx.multigpu.launch_ranks"
+
+
+def test_bench_runs_as_ranks_of_torch_distributed_run(tmp_path):
+    """The driver's command for N > 1: torch.distributed.run starts the ranks, bench.py joins as one."""
+    port = _free_port()
+    env = dict(os.environ, JPEGX_CTL_DIR=str(tmp_path), OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(REPO, "bench.py"), "--gpus", "2", "--dry-run", "--planes-total", "1024"]
+    line = _bench_line(subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600))
+    assert line["dry_run"] and line["n_gpus"] == 2 and line["shards"] == [[0, 512], [512, 1024]]
+    assert line["launcher"] == "external"
+
+
+GLOO_WORKER = r'''
 import os, sys
 import numpy as np
 import torch
@@ -37,31 +149,40 @@ import torch.distributed as dist
 sys.path.insert(0, %(repo)r); sys.path.insert(0, %(pkg)r)
 import oracle
 from jpegx import synth
-from jpegx.multigpu import gather_stream, shard_block_rows, shard_planes
+from jpegx.multigpu import GatherPlan, shard_block_rows, shard_planes
+
+def gather_to_root(local):
+    """rank-ordered gather of unequal int16 spans (the layout jpegx_comm_gather_bytes produces)"""
+    flat = torch.from_numpy(np.ascontiguousarray(local).reshape(-1).view(np.uint8))
+    sizes = torch.zeros(world, dtype=torch.int64); sizes[rank] = flat.numel()
+    dist.all_reduce(sizes)
+    cap = int(sizes.max())
+    pad = torch.cat([flat, flat.new_zeros(cap - flat.numel())])
+    bufs = [torch.empty(cap, dtype=torch.uint8) for _ in range(world)] if rank == 0 else None
+    dist.gather(pad, bufs, dst=0)
+    if rank != 0:
+        return None
+    return np.concatenate([b[:int(n)].numpy() for b, n in zip(bufs, sizes)]).view(np.int16)
 
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
-# (1) a batch of 5 independent planes (uneven split) -------------------------------------------
+ok = True
+# (1) a batch of 5 independent planes (uneven split), laid out by GatherPlan ---------------------
 lo, hi = shard_planes(5, world, rank)
 local = [oracle.forward_f32(synth.generate_plane("noise", 32, 64, seed=0, plane=p), "qtable") for p in range(lo, hi)]
-local = torch.from_numpy(np.stack(local)) if local else torch.empty(0, dtype=torch.int16)
-parts = gather_stream(local, dst=0)
-ok = True
+got = gather_to_root(np.stack(local))
 if rank == 0:
     full = np.stack([oracle.forward_f32(synth.generate_plane("noise", 32, 64, seed=0, plane=p), "qtable") for p in range(5)])
-    got = torch.cat(parts).numpy().reshape(full.shape)
-    ok = ok and np.array_equal(got, full)
-else:
-    ok = ok and parts is None
+    ok = ok and np.array_equal(got.reshape(full.shape), full)
+    plan = GatherPlan(5, world, full[0].nbytes, 2)
+    ok = ok and plan.spans == [shard_planes(5, world, r) for r in range(world)]
 # (2) block-row ranges of one tall plane --------------------------------------------------------
 H, W = 88, 64
 y0, y1 = shard_block_rows(H, world, rank)
 plane = synth.generate_plane("smooth", H, W, seed=3)
-mine = torch.from_numpy(oracle.forward_f32(plane[y0:y1], "qtable"))
-parts = gather_stream(mine, dst=0)
+got = gather_to_root(oracle.forward_f32(plane[y0:y1], "qtable"))
 if rank == 0:
-    got = torch.cat(parts).numpy().reshape(H // 8, W // 8, 64)
-    ok = ok and np.array_equal(got, oracle.forward_f32(plane, "qtable"))
+    ok = ok and np.array_equal(got.reshape(H // 8, W // 8, 64), oracle.forward_f32(plane, "qtable"))
 flag = torch.tensor([1 if ok else 0])
 dist.all_reduce(flag, op=dist.ReduceOp.MIN)
 dist.destroy_process_group()
@@ -70,13 +191,10 @@ sys.exit(0 if int(flag.item()) == 1 else 1)
 
 
 def test_two_rank_gloo_shard_and_gather(tmp_path):
-    script = tmp_path / "worker.py"
-    script.write_text(WORKER % {"repo": REPO, "pkg": PKG})
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+    script = _write(tmp_path, "gloo_worker.py", GLOO_WORKER)
+    port = _free_port()
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)]
+           "--master-addr", "127.0.0.1", "--master-port", str(port), script]
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
