@@ -40,6 +40,41 @@ constexpr I64 kQT = make_qt();
 __device__ const double c_dct[64] = {JPEGX_TABLE_DCT_MATRIX};     // C[k][n]
 __device__ const double c_cn[64] = {JPEGX_TABLE_DCT_NORMALIZED};  // Cn[k][n]
 __device__ const double c_dinv[8] = {JPEGX_TABLE_NORM_DIAG};
+constexpr D64 make_cn_transposed()
+{
+    D64 a{{JPEGX_TABLE_DCT_NORMALIZED}}, t{};
+    for (int k = 0; k < 8; ++k)
+        for (int n = 0; n < 8; ++n) t.v[n * 8 + k] = a.v[k * 8 + n];
+    return t;
+}
+__device__ const D64 c_cnT = make_cn_transposed();               // CnT[n][k] = Cn[k][n]: column n of Cn contiguous
+// Everything the inverse exact tier looks up, packed into 1 KiB so that ONE LDS-DMA instruction issued
+// with the coefficient tile brings it into LDS: the tier then runs without a single vector memory load
+// (under a saturated HBM stream such a load queues behind the streaming traffic for microseconds, which
+// at 10-16 waves per CU costs far more than the tier's arithmetic).
+struct InvExactTab {
+    double cnT[64];          // CnT[n][k] = Cn[k][n]
+    double dinv[8];
+    unsigned char pz[64];    // pz[t][k] = zigzag position of the natural coefficient (row k, column t)
+    unsigned char q[64];     // q[t][k]  = luminance table entry (row k, column t)
+    unsigned char pad[1024 - 512 - 64 - 64 - 64];
+};
+constexpr InvExactTab make_inv_exact_tab()
+{
+    InvExactTab t{};
+    D64 cn = make_cn_transposed(), di{{JPEGX_TABLE_NORM_DIAG}};
+    I64 zi = make_zzinv(), qt = make_qt();
+    for (int n = 0; n < 64; ++n) t.cnT[n] = cn.v[n];
+    for (int k = 0; k < 8; ++k) t.dinv[k] = di.v[k];
+    for (int c = 0; c < 8; ++c)
+        for (int k = 0; k < 8; ++k) {
+            t.pz[c * 8 + k] = (unsigned char)zi.v[k * 8 + c];
+            t.q[c * 8 + k] = (unsigned char)qt.v[k * 8 + c];
+        }
+    return t;
+}
+static_assert(sizeof(InvExactTab) == 1024, "one DMA instruction = 64 lanes x 16 B");
+__device__ __attribute__((aligned(16))) const InvExactTab c_inv_exact = make_inv_exact_tab();
 __device__ const D64 c_rq64 = make_rq64();
 __device__ const I64 c_qt = make_qt();
 __device__ const I64 c_zz = make_zz();

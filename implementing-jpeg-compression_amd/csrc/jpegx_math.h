@@ -118,17 +118,24 @@ JPEGX_HD void jpegx_idct8x8_f32(float (&v)[64])
 // 16 u S = 2^-20 S is used (margin for second-order terms).
 JPEGX_HD float jpegx_fwd_err_bound(float S) { return S * 0x1p-20f; }
 
-// Same for the inverse, for a dequantised block with DC magnitude D = |Z00| and AC abs sum
-// A = sum_{n != 0} |Z_n|.  Each pass scales AC terms by 1/4 and puts <= 6 roundings on an AC
-// term's path (1.5 u per unit of |Z|); the k = 0 input of a 1-D transform is scaled by exactly
-// 1/8 (a power of two) and only meets the 3 roundings of the final additions (3/8 u per unit).
-//   pass 1, column j :  e1 <= 3/8 u |Z0j| + 3/2 u T'_j                (T'_j = sum_{k>=1} |Zkj|)
-//   pass 2, row i    :  1/8 e1(col 0) + 1/4 sum_{k>=1} e1(col k) + 3/8 u |m_i0| + 3/2 u sum_{k>=1} |m_ik|
-//   with |m_i0| <= D/8 + T'_0/4 and |m_ik| <= |Z0k|/8 + T'_k/4 this is
-//       u (3/32 D + 9/32 (T'_0 + sum_{k>=1}|Z0k|) + 3/4 sum_{k>=1} T'_k)  <=  u (0.094 D + 0.75 A);
-// an inexact fp32 dequantisation product adds <= u (D/64 + A/16).  First order
-// u (0.11 D + 0.8125 A); the bound used is u (0.125 D + 0.875 A).
-JPEGX_HD float jpegx_inv_err_bound(float D, float A) { return fmaf(D, 0x1p-27f, A * 0x1.cp-25f); }
+// Same for the inverse.  A 1-D inverse pass (jpegx_idct8_f32) scales its k = 0 input by exactly 1/8 (a
+// power of two; that term only meets the 3 roundings of the final additions) and every k >= 1 input by
+// c/4 with |c| <= 1 (<= 6 roundings on its path: the fp32 rounding of the constant, the product, three
+// fma's, the final addition).  A coefficient Z[k][l] reaches an output sample through the column pass
+// (index k) and then the row pass (index l), so its share of |x32 - x64| is bounded by
+//   |Z00|            * 1/8 * 1/8 * (3 + 3) u  = 3/32 u   (D  = |Z00|)
+//   |Z0l|, |Zk0|     * 1/8 * 1/4 * (3 + 6) u  = 9/32 u   (A1 = abs sum of the 14 other first-row/column terms)
+//   |Zkl|, k, l >= 1 * 1/4 * 1/4 * (6 + 6) u  = 3/4  u   (A2 = abs sum of the 49 inner terms)
+// (pass 2 works on the computed pass-1 values; the products of two error terms are O(u^2 A), far below
+// the 2^-10 relative margin added here).  `dq` = number of roundings in the fp32 dequantisation: 0 when
+// z * q is exact in fp32 (modes none / discard / qtable: integers below 2^24), 2 for mode divide (the
+// fp32 rounding of the divisor and of the product); each one adds 1/64, 1/32, 1/16 u to the three classes.
+JPEGX_HD float jpegx_inv_err_bound(float D, float A1, float A2, float dq)
+{
+    const float u = 0x1.004p-24f;   // 2^-24 (1 + 2^-10)
+    const float cD = fmaf(dq, 1.0f / 64, 3.0f / 32), c1 = fmaf(dq, 1.0f / 32, 9.0f / 32), c2 = fmaf(dq, 1.0f / 16, 3.0f / 4);
+    return u * fmaf(D, cD, fmaf(A1, c1, A2 * c2));
+}
 
 // ---------------------------------------------------------------------------------------------
 // fp64 exact tier (reference operation order)

@@ -16,7 +16,8 @@ import numpy as np
 from . import synth  # noqa: F401  (re-export: jpegx.synth.generate_plane)
 
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(_PKG_ROOT, "libjpegx.so")
+# JPEGX_LIB_PATH: load another build of the same library (A/B measurements of compiler flags)
+LIB_PATH = os.environ.get("JPEGX_LIB_PATH") or os.path.join(_PKG_ROOT, "libjpegx.so")
 
 Q_NONE, Q_DISCARD, Q_DIVIDE, Q_QTABLE = 0, 1, 2, 3
 MODE_BY_NAME = {"none": Q_NONE, "discard": Q_DISCARD, "divide": Q_DIVIDE, "qtable": Q_QTABLE}

@@ -82,14 +82,18 @@ int emul_inverse(const int16_t *in, int H, int W, int mode, double param, int32_
     for (int by = 0; by < H / 8; ++by)
         for (int bx = 0; bx < wb; ++bx) {
             const int16_t *z = in + ((size_t)by * wb + bx) * 64;
-            float v[64]; double a[64]; float S = 0.f, Sac = 0.f;
+            float v[64]; double a[64]; float A1 = 0.f, A2 = 0.f;
             for (int p = 0; p < 64; ++p) {
                 int n = T_ZZ[p];
                 double d = jpegx_restore_ref((double)z[p], n, mode, param, T_QT);
-                a[n] = d; v[n] = (float)d; S += fabsf(v[n]);
-                if (n != 0) Sac += fabsf(v[n]);
+                a[n] = d;
+                // the kernel's fp32 dequantisation: (float)z * fp32 multiplier (k_inverse_fused)
+                v[n] = (mode == JPEGX_QM_QTABLE) ? (float)z[p] * (float)T_QT[n]
+                       : (mode == JPEGX_QM_DIVIDE ? (float)z[p] * (float)param : (float)z[p]);
+                if (n == 0) continue;
+                if (n < 8 || (n & 7) == 0) A1 += fabsf(v[n]); else A2 += fabsf(v[n]);
             }
-            const float E = jpegx_inv_err_bound(fabsf(v[0]), Sac);
+            const float E = jpegx_inv_err_bound(fabsf(v[0]), A1, A2, mode == JPEGX_QM_DIVIDE ? 2.f : 0.f);
             jpegx_idct8x8_f32(v);
             double u[8], m[64], y64[64], w[8];
             for (int j = 0; j < 8; ++j) {       // columns first
