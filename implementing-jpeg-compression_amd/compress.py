@@ -14,21 +14,19 @@ def compress(input_fname, output_fname, block_size=4, dct_size=8, transform="DCT
 
 
 def build_parser():
-    p = argparse.ArgumentParser(description="Given an image, compress it using JPEG algorithm")
-    p.add_argument("infile", type=str, help="a path to the file to compress")
-    p.add_argument("outfile", type=str, help="a destination path")
-    p.add_argument("--block_size", action="store", type=int, default=4, help="size of sub-sampling block")
-    p.add_argument("--dct_size", action="store", type=int, default=8, help="size of block for DCT transform")
+    p = argparse.ArgumentParser(description="Compress an image file with the JPEG-like block codec")
+    p.add_argument("infile", type=str, help="image to read (any format Pillow opens)")
+    p.add_argument("outfile", type=str, help="where to write the compressed stream")
+    p.add_argument("--block_size", action="store", type=int, default=4, help="edge of the square tiles averaged by the sub-sampling stage (1 = off)")
+    p.add_argument("--dct_size", action="store", type=int, default=8, help="edge of the transform blocks")
     p.add_argument("--transform", action="store", type=str, default="DCT",
-                   help="type of discrete transform (DCT vs DFT)")
+                   help="block transform: DCT or DFT")
     p.add_argument("--quantization", action="store", type=str, default="qtable",
-                   help="type of quantization to use: on of none, discard, divide, qtable ")
+                   help="quantiser: none, discard, divide or qtable")
     p.add_argument("--qkeep", action="store", type=int, default=2,
-                   help="specifies how many coefficients to keep along both axes,"
-                        "applied only if quantization is set to \"discard\"")
+                   help="with --quantization discard: keep the top-left qkeep x qkeep coefficients of a block")
     p.add_argument("--qdivisor", action="store", type=int, default=40,
-                   help="specifies an integer used to divide coefficients by,"
-                        "applied only if quantization is set to \"divide\"")
+                   help="with --quantization divide: the divisor applied to every coefficient")
     return p
 
 

@@ -213,6 +213,10 @@ __global__ __launch_bounds__(64) void k_rle_emit(const int16_t *__restrict__ zz,
     __shared__ __attribute__((aligned(16))) unsigned char lds[EMIT_STAGE_BYTES];
     unsigned *stage = reinterpret_cast<unsigned *>(lds);
     const Workspace W = carve(const_cast<void *>(ws), nblk);
+    // the sizes pass flagged an amplitude beyond 15 bits: such a block can exceed the staging area (and
+    // the reference raises BadRleCodeError for it), so nothing is emitted -- whether or not the caller
+    // looked at jpegx_entropy_total's return code
+    if (*W.error != 0) return;
     const int lane = threadIdx.x, g0 = blockIdx.x * 64, g = g0 + lane;
     stage_tile(zz, g0, nblk, lane, lds);
     unsigned w[32];
@@ -332,6 +336,16 @@ int jpegx_entropy_total(const void *d_workspace, unsigned long long *h_total, jp
     *h_total = head[0];
     if ((unsigned)(head[1] & 0xFFFFFFFFull) != 0)
         return fail(JPEGX_E_INVALID, "BadRleCodeError: an amplitude needs more than 15 bits (|a| > 16383)");
+    return JPEGX_OK;
+}
+
+int jpegx_entropy_block_sizes(const void *d_workspace, long long nblocks, uint32_t *h_sizes, jpegx_stream_t stream)
+{
+    if (!d_workspace || !h_sizes) return fail(JPEGX_E_INVALID, "null pointer");
+    if (nblocks <= 0 || nblocks > 0x7FFFFFC0LL) return fail(JPEGX_E_INVALID, "block count must be in 1 .. 2^31-64");
+    const Workspace W = carve(const_cast<void *>(d_workspace), nblocks);
+    HIP_TRY(hipMemcpyAsync(h_sizes, W.block_bytes, (size_t)nblocks * 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     return JPEGX_OK;
 }
 

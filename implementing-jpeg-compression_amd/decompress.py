@@ -11,8 +11,8 @@ def decompress(input_path, output_path):
 
 
 if __name__ == "__main__":
-    parser = argparse.ArgumentParser(description="Given an image, compress it using JPEG algorithm")
-    parser.add_argument("infile", type=str, help="a path to the file to compress")
-    parser.add_argument("outfile", type=str, help="a destination path")
+    parser = argparse.ArgumentParser(description="Decode a stream written by compress.py and save it as an image")
+    parser.add_argument("infile", type=str, help="compressed stream to read")
+    parser.add_argument("outfile", type=str, help="image file to write (format from the extension)")
     args = parser.parse_args()
     decompress(args.infile, args.outfile)

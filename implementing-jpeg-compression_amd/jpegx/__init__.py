@@ -96,6 +96,7 @@ SIGNATURES = {
     "jpegx_entropy_workspace_bytes": [_c.c_longlong],
     "jpegx_entropy_sizes": [_vp, _c.c_longlong, _vp, _vp],
     "jpegx_entropy_total": [_vp, _c.POINTER(_c.c_ulonglong), _vp],
+    "jpegx_entropy_block_sizes": [_vp, _c.c_longlong, _vp, _vp],
     "jpegx_entropy_emit": [_vp, _c.c_longlong, _vp, _vp, _vp],
     "jpegx_host_entropy_encode": [_vp, _c.c_longlong, _vp, _sz, _c.POINTER(_sz)],
     "jpegx_host_entropy_decode": [_vp, _sz, _c.c_longlong, _vp],
@@ -461,6 +462,25 @@ def entropy_encode(zz):
     check(lib().jpegx_host_entropy_encode(z.ctypes.data, nblocks, out.ctypes.data, out.size, ctypes.byref(n)),
           "jpegx_host_entropy_encode")
     return out[:n.value].tobytes()
+
+
+def entropy_block_sizes(zz):
+    """Bytes of every block's code string as the device sizes pass computes them (uint32 per block)."""
+    z = np.ascontiguousarray(zz, dtype=np.int16)
+    if z.ndim < 1 or z.shape[-1] != 64 or z.size == 0:
+        raise JpegxError("expected a (..., 64) coefficient stream, got %r" % (z.shape,))
+    nblocks = z.size // 64
+    L = lib()
+    dzz, dws = DeviceBuffer(z.nbytes), DeviceBuffer(L.jpegx_entropy_workspace_bytes(nblocks))
+    try:
+        dzz.upload(z)
+        check(L.jpegx_entropy_sizes(dzz.ptr, nblocks, dws.ptr, None), "jpegx_entropy_sizes")
+        out = np.empty(nblocks, dtype=np.uint32)
+        check(L.jpegx_entropy_block_sizes(dws.ptr, nblocks, out.ctypes.data, None), "jpegx_entropy_block_sizes")
+        return out
+    finally:
+        dzz.free()
+        dws.free()
 
 
 def compress_plane(plane, block_size=1, mode="qtable", param=0.0):

@@ -8,7 +8,7 @@ import numpy as np
 
 from .base import AlgorithmStep
 
-_MODES = {"none": "none", "discard": "discard", "divide": "divide", "qtable": "qtable"}
+_MODES = ("none", "discard", "divide", "qtable")
 
 
 class Quantization(AlgorithmStep):

@@ -1,75 +1,96 @@
-"""Step 8: bit packing of the run-length codes (reference: pipeline/rle_byte_stream.py).
+"""Step 8: the run-length codes as a byte stream (behaviour of the reference's
+pipeline/rle_byte_stream.py + util.RunLengthCode.as_bitsring, done with NumPy bit arrays).
 
-4-bit run, 4-bit size, then a sign bit ('1' = positive) and the magnitude bits; EOB is a zero
-byte and the stream is padded to a byte boundary after every EOB.  Uses util.Bits in place of
-the reference's 3rd-party bitarray."""
-from util import Bits, RunLengthCode
+Layout per code: 4-bit run, 4-bit size, then -- unless the code is a ``(15, 0, 0)`` zero chain -- a sign
+bit ('1' = strictly positive) followed by ``|amplitude|`` in binary without leading zeros.  The end
+of a block is one zero byte and the stream is padded with zero bits to the next byte boundary after
+it, so every block starts on a byte.  The device form of this stage is csrc/jpegx_entropy.hip.
+"""
+import numpy as np
+
+from util import BadRleCodeError
 from .base import AlgorithmStep
 
+_ROOM = 40          # bits of room behind the header byte in the scratch bit matrix
 
-class BitDecoder:
-    def __init__(self, array):
-        self._array = array
-        self._pos = 0
 
-    def read(self, n):
-        chunk = self._array[self._pos:self._pos + n]
-        self._pos += n
-        return chunk
-
-    def read_quad(self):
-        return self.read(4)
-
-    def decode_unsigned(self, n):
-        return int(self.read(n).to01(), base=2)
-
-    def decode_signed(self, n):
-        text = self.read(n).to01()
-        magnitude = int(text[1:], base=2)
-        return magnitude if text[0] == "1" else -magnitude
-
-    def skip_padding(self):
-        self._pos += (-self._pos) % 8
-
-    def is_end(self):
-        return self._pos >= len(self._array)
+def _validated(tuples_list):
+    """(run, size, amplitude) columns of the code list; the same rejections as util.RunLengthCode."""
+    codes = [t if len(t) == 3 else (t[0], t[1], 0) for t in tuples_list]
+    for r, s, a in codes:
+        if (s == 0 and a != 0) or not 0 <= r <= 15 or not 0 <= s <= 15 or (0 < r < 15 and s == 0 and a == 0):
+            raise BadRleCodeError("({}, {}, {})".format(r, s, a))
+    if not codes:
+        return (np.zeros(0, dtype=np.int64),) * 3
+    run, size, amp = (np.array(col) for col in zip(*codes))
+    if np.iscomplexobj(amp):
+        amp = amp.real
+    return run.astype(np.int64), size.astype(np.int64), np.round(amp).astype(np.int64)
 
 
 class RleBytestream(AlgorithmStep):
     step_index = 8
 
     def execute(self, tuples_list):
-        pieces = []
-        nbits = 0
-        for t in tuples_list:
-            code = RunLengthCode(*t)
-            text = code.as_bitsring().to01()
-            pieces.append(text)
-            nbits += len(text)
-            if code.is_EOB():
-                pad = (-nbits) % 8
-                pieces.append("0" * pad)
-                nbits += pad
-        return Bits("".join(pieces)).tobytes()
+        run, size, amp = _validated(tuples_list)
+        if run.size == 0:
+            return b""
+        is_end = (run == 0) & (size == 0)
+        has_amp = ~is_end & ~((run == 15) & (size == 0))
+        mag = np.abs(amp)
+        digits = np.ones(mag.shape, dtype=np.int64)     # binary digits of |amplitude|, at least one
+        rest = mag >> 1
+        while rest.any():
+            digits += rest > 0
+            rest = rest >> 1
+        if digits.max() + 1 > _ROOM:
+            raise BadRleCodeError("amplitude too wide: {}".format(int(mag.max())))
+        nbits = 8 + np.where(has_amp, 1 + digits, 0)
+        # one row of bits per code: header byte, sign, magnitude (MSB first), zeros behind
+        word = ((run << 4) | size) << _ROOM
+        word |= np.where(has_amp, (((amp > 0).astype(np.int64) << digits) | mag) << (_ROOM - 1 - digits), 0)
+        rows = np.unpackbits(word.astype(">u8").view(np.uint8).reshape(-1, 8), axis=1)[:, 64 - 8 - _ROOM:]
+        # where each code starts: running total of bits, rounded up to a byte behind each end marker
+        block = np.cumsum(is_end) - is_end
+        bits_of_block = np.bincount(block, weights=nbits).astype(np.int64)
+        padded = (bits_of_block + 7) // 8 * 8
+        start = (np.cumsum(padded) - padded)[block] + (np.cumsum(nbits) - nbits) - (np.cumsum(bits_of_block) - bits_of_block)[block]
+        stream = np.zeros(int(padded.sum()), dtype=np.uint8)
+        col = np.arange(rows.shape[1])
+        live = col[None, :] < nbits[:, None]
+        stream[(start[:, None] + col[None, :])[live]] = rows[live]
+        return np.packbits(stream).tobytes()
 
     def invert(self, bytestream):
-        bits = Bits()
-        bits.frombytes(bytestream)
-        return [code.as_tuple() for code in self._codes(bits)]
+        data = bytes(bytestream)
+        out = []
+        window, have, pos = 0, 0, 0                 # upcoming bits as an int, how many of them, next byte to load
 
-    def _pad_bitarray(self, a):
-        while len(a) % 8 > 0:
-            a.append(False)
+        def take(n):
+            nonlocal window, have, pos
+            while have < n and pos < len(data):
+                window = (window << 8) | data[pos]
+                pos += 1
+                have += 8
+            if have < n:                            # past the end the reference's slices just come back short
+                window <<= n - have
+                have = n
+            have -= n
+            value = window >> have
+            window &= (1 << have) - 1
+            return value
 
-    def _codes(self, bits):
-        decoder = BitDecoder(bits)
-        while not decoder.is_end():
-            run_len = decoder.decode_unsigned(4)
-            size = decoder.decode_unsigned(4)
-            if run_len == 0 and size == 0:
-                decoder.skip_padding()
-                yield RunLengthCode.EOB()
-            elif run_len == 15 and size == 0:
-                yield RunLengthCode(15, 0, 0)
+        while pos < len(data) or have > 0:
+            run, size = take(4), take(4)
+            if run == 0 and size == 0:
+                window, have = 0, 0                 # drop the padding: the next block starts on a byte
+                out.append((0, 0))
+            elif run == 15 and size == 0:
+                out.append((15, 0, 0))
             else:
-                yield RunLengthCode(run_len, size, decoder.decode_signed(size))
+                if size == 0:                       # the reference fails here too: int('', base=2)
+                    raise ValueError("run-length code ({}, 0) has no amplitude bits".format(run))
+                bits = take(size)
+                magnitude = bits & ((1 << (size - 1)) - 1)
+                out.append((run, size, magnitude if bits >> (size - 1) else -magnitude))
+        return out

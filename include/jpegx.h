@@ -201,6 +201,11 @@ int jpegx_unzigzag(const void *d_in, int H, int W, int elem_size, void *d_out, p
 size_t jpegx_entropy_workspace_bytes(long long nblocks);
 int jpegx_entropy_sizes(const int16_t *d_zz, long long nblocks, void *d_workspace, jpegx_stream_t stream);
 int jpegx_entropy_total(const void *d_workspace, unsigned long long *h_total, jpegx_stream_t stream);
+/* bytes of every block's code string (after jpegx_entropy_sizes; synchronises): block b starts at the sum
+ * of the sizes before it -- the index a decoder needs to find block boundaries without parsing          */
+int jpegx_entropy_block_sizes(const void *d_workspace, long long nblocks, uint32_t *h_sizes,
+                              jpegx_stream_t stream);
+/* enqueue; writes nothing at all when the sizes pass flagged an amplitude beyond 15 bits */
 int jpegx_entropy_emit(const int16_t *d_zz, long long nblocks, const void *d_workspace, uint8_t *d_out,
                        jpegx_stream_t stream);
 /* host convenience; h_out may be NULL to query the size only */

@@ -58,3 +58,35 @@ def test_compress_plane_all_on_device(gpu):
     assert gpu.compress_plane(a, 1, "qtable") == oracle.rle_bytestream(oracle.forward_f32(a, "qtable"))
     pooled = oracle.mean_pool(a, 2).astype(np.float32)
     assert gpu.compress_plane(a, 2, "qtable") == oracle.rle_bytestream(oracle.forward_f32(pooled, "qtable"))
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_device_block_sizes_follow_from_the_reference_tuples(gpu, golden, case):
+    """k_rle_sizes against the reference's own step-7 output (tests/golden rle_*): the bytes of every block
+    follow from its tuples and the bit layout; the device stream has exactly that total length."""
+    from test_oracle_golden import block_bytes_from_tuples, reference_tuples
+    c = golden(case)
+    for suffix, _, _ in MODES:
+        zz = c["zz_" + suffix]
+        expect = block_bytes_from_tuples(reference_tuples(c["rle_" + suffix]))
+        assert np.array_equal(gpu.entropy_block_sizes(zz), expect), (case, suffix)
+        assert len(gpu.entropy_encode(zz)) == int(expect.sum())
+
+
+def test_emit_after_a_flagged_sizes_pass_writes_nothing(gpu):
+    """A C-ABI caller that ignores jpegx_entropy_total's error must not get an out-of-bounds emit: blocks with
+    16-bit amplitudes can exceed the emit kernel's staging area, so the kernel refuses to run."""
+    import ctypes
+    L = gpu.lib()
+    z = np.full((130, 64), 32767, np.int16)              # every coefficient needs 16 bits
+    dzz, dws = gpu.DeviceBuffer(z.nbytes), gpu.DeviceBuffer(L.jpegx_entropy_workspace_bytes(130))
+    dout = gpu.DeviceBuffer(130 * 256)
+    dzz.upload(z)
+    gpu.check(L.jpegx_memset(dout.ptr, 0xAB, 130 * 256, None))
+    gpu.check(L.jpegx_entropy_sizes(dzz.ptr, 130, dws.ptr, None))
+    total = ctypes.c_ulonglong(0)
+    assert L.jpegx_entropy_total(dws.ptr, ctypes.byref(total), None) == -1
+    assert b"15 bits" in L.jpegx_last_error()
+    gpu.check(L.jpegx_entropy_emit(dzz.ptr, 130, dws.ptr, dout.ptr, None))      # enqueues, writes nothing
+    gpu.check(L.jpegx_device_synchronize())
+    assert np.all(dout.download((130 * 256,), np.uint8) == 0xAB)

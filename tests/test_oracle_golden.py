@@ -1,5 +1,7 @@
 """The oracle (oracle/jpegx_oracle.c) against every golden vector produced by the unmodified
 reference, and against the reference's own known-answer tests for this path.  CPU only."""
+import os
+
 import numpy as np
 import pytest
 
@@ -126,3 +128,86 @@ def test_rle_bytestream_matches_the_host_mirror(golden):
         want = RleBytestream(None).execute(RunLengthEncoding(None).execute(zz.astype(float)))
         blob, sizes = oracle.rle_bytestream(zz, want_block_bytes=True)
         assert blob == want and int(sizes.sum()) == len(blob)
+
+
+# ---- step 7 and the container pinned by outputs of the reference itself (make_golden.py) -------
+def reference_tuples(rows):
+    """(K, 3) int32 fixture rows -> the reference's tuple list ((0, 0, 0) rows are the (0, 0) end markers)."""
+    return [(0, 0) if (r == 0 and s == 0) else (r, s, a) for r, s, a in np.asarray(rows).tolist()]
+
+
+def block_bytes_from_tuples(tuples):
+    """Bytes of every block's code string implied by the reference's step-7 tuples and its bit layout
+    (rle_byte_stream.py:48-59, util.py:203-221): 8 header bits per code, plus `size` amplitude bits unless the
+    code is a zero chain or the end marker; each block is padded to a byte."""
+    sizes, bits = [], 0
+    for t in tuples:
+        bits += 8
+        if len(t) == 3 and not (t[0] == 15 and t[1] == 0):
+            bits += t[1]
+        if len(t) == 2:
+            sizes.append((bits + 7) // 8)
+            bits = 0
+    return np.array(sizes, dtype=np.uint32)
+
+
+def test_rle_block_fixture_from_the_reference():
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "rle_blocks.npz"))
+    for i in range(int(fx["n"])):
+        want = reference_tuples(fx["codes_%d" % i])
+        assert oracle.rle_block_tuples(fx["block_%d" % i]) == want, i
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_rle_tuples_of_every_golden_stream(golden, case):
+    """oracle.rle_block_tuples block by block == RunLengthEncoding.execute of the reference on the same
+    zigzag stream; the byte stream's per-block sizes and total follow from those tuples."""
+    c = golden(case)
+    for suffix, _, _ in MODES:
+        zz = c["zz_" + suffix]
+        want = reference_tuples(c["rle_" + suffix])
+        got = [t for blk in zz.reshape(-1, 64) for t in oracle.rle_block_tuples(blk)]
+        assert got == want, (case, suffix)
+        blob, sizes = oracle.rle_bytestream(zz, want_block_bytes=True)
+        expect = block_bytes_from_tuples(want)
+        assert np.array_equal(sizes, expect) and len(blob) == int(expect.sum())
+
+
+def test_host_rle_step_reproduces_the_reference_tuples(golden):
+    from pipeline import Configuration
+    from pipeline.rle_byte_stream import RleBytestream
+    from pipeline.run_length_encoding import RunLengthEncoding
+    for case in CASES:
+        c = golden(case)
+        h, w = c["pre"].shape
+        cfg = Configuration(width=w, height=h, block_size=1, dct_size=8)
+        for suffix, _, _ in MODES:
+            zz = c["zz_" + suffix]
+            want = reference_tuples(c["rle_" + suffix])
+            step = RunLengthEncoding(cfg)
+            assert step.execute(zz.astype(np.float64)) == want
+            assert np.array_equal(step.invert(want), zz)
+            blob = RleBytestream(cfg).execute(want)
+            assert blob == oracle.rle_bytestream(zz) and RleBytestream(cfg).invert(blob) == want
+
+
+def test_container_bytes_match_the_reference():
+    """file_format.create_header / generate_data / read_data against the header and file bytes the reference
+    wrote for seven configurations (tests/golden/container.npz)."""
+    import json
+    import file_format
+    from pipeline import CompressedData, Configuration, QuantizationMethod
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "container.npz"))
+    for i in range(int(fx["n"])):
+        d = json.loads(fx["config_%d" % i].tobytes().decode())
+        q = QuantizationMethod(d["q"][0], **d["q"][1]) if d["q"] is not None else None
+        cfg = Configuration(width=d["width"], height=d["height"], block_size=d["block_size"], dct_size=d["dct_size"],
+                            transform=d["transform"], quantization=q)
+        assert file_format.create_header(cfg) == fx["header_%d" % i].tobytes(), d
+        parts = [fx["%s_%d" % (n, i)].tobytes() for n in ("y", "cb", "cr")]
+        assert file_format.generate_data(cfg, CompressedData(*parts)) == fx["file_%d" % i].tobytes(), d
+        back, data = file_format.read_data(fx["file_%d" % i].tobytes())
+        assert (back.width, back.height, back.block_size, back.dct_size, back.transform) == \
+            (d["width"], d["height"], d["block_size"], d["dct_size"], d["transform"])
+        assert back.quantization.name == (d["q"][0] if d["q"] else "none")
+        assert [data.y, data.cb, data.cr] == parts
