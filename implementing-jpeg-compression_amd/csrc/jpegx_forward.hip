@@ -761,13 +761,24 @@ double expected_exact_share(const QuantParams &qp)
     return 1.0 - keep;
 }
 
+float max_abs_multiplier(const QuantParams &qp)
+{
+    float m = 0.f;
+    for (int n = 0; n < 64; ++n) m = fmaxf(m, fabsf(qp.rq32[n]));
+    return m;
+}
+
 template <int BS, bool NT, int STAGED = 0>
 int launch_forward(const float *d_in, int H, int W, ptrdiff_t pitch, const QuantParams &qp, unsigned flags,
                    int16_t *d_out, hipStream_t st)
 {
     const int wb = W / 8, nblk = (H / 8) * wb;
     const dim3 grid((nblk + 63) / 64), block(64);
-    const bool pixel = (flags & JPEGX_F_PIXEL_INPUT) != 0;
+    // The PIXEL variants pack without saturating: |coefficient| <= 16320 for 8-bit content, so the
+    // quantised value fits int16 only while the multiplier is at most 2 (a divisor below 0.5 goes
+    // through the generic, saturating variant; the reference raises BadRleCodeError on such amplitudes
+    // and so does the entropy stage behind this kernel).
+    const bool pixel = (flags & JPEGX_F_PIXEL_INPUT) != 0 && max_abs_multiplier(qp) <= 2.0f;
     // DC is an exact integer multiple of 2^-8 and rq[0] a power of two -> DC/q needs no tie check
     const bool dc_exact = pixel && is_pow2_float(qp.rq32[0]) &&
                           (qp.mode != JPEGX_Q_DIVIDE || (double)qp.rq32[0] * qp.param == 1.0);
@@ -870,7 +881,7 @@ int jpegx_forward_fused_planes(const jpegx_plane_desc *planes, int nplanes, int 
         if (wg > 0x7FFFFFFFLL) return fail(JPEGX_E_INVALID, "forward_planes: more than 2^31 workgroups in one launch");
     }
     tab.n = nplanes;
-    const bool pixel = (flags & JPEGX_F_PIXEL_INPUT) != 0;
+    const bool pixel = (flags & JPEGX_F_PIXEL_INPUT) != 0 && max_abs_multiplier(qp) <= 2.0f;
     const bool dc_exact = pixel && is_pow2_float(qp.rq32[0]) && (qp.mode != JPEGX_Q_DIVIDE || (double)qp.rq32[0] * qp.param == 1.0);
     const bool nt = !(flags & JPEGX_F_TUNE_NO_NT);
     const dim3 grid((unsigned)wg), block(64);
@@ -902,6 +913,8 @@ int jpegx_forward_fused_u8(const uint8_t *d_in, int H, int W, ptrdiff_t pitch, i
     QuantParams qp;
     rc = fill_forward_params(mode, param, &qp);
     if (rc) return rc;
+    if (max_abs_multiplier(qp) > 2.0f)   // the uint8 kernels pack without saturating (see launch_forward)
+        return fail(JPEGX_E_UNSUPPORTED, "forward_u8: a divisor below 0.5 can overflow int16; use the fp32 entry (it saturates)");
     if (flags & JPEGX_F_TUNE_SKIP_EXACT) qp.tune |= 1;
     const int wb = W / 8, nblk = (H / 8) * wb;
     const dim3 grid((nblk + 63) / 64), block(64);

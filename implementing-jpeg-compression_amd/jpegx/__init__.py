@@ -262,8 +262,11 @@ def forward_fused_u8_device(in_ptr, height, width, out_ptr, mode="qtable", param
                                        float(param), flags, out_ptr, stream), "jpegx_forward_fused_u8")
 
 
-def u8_path_ok(width_out, pool, pitch_bytes):
-    """Shapes the uint8 kernels accept: block_size 1 (W % 16 == 0), 2 or 4, 16-byte aligned rows."""
+def u8_path_ok(width_out, pool, pitch_bytes, mode="qtable", param=0.0):
+    """What the uint8 kernels accept: block_size 1 (W % 16 == 0), 2 or 4, 16-byte aligned rows, and a
+    quantiser whose multiplier is at most 2 (they pack to int16 without saturating)."""
+    if mode_of(mode) == Q_DIVIDE and abs(float(param)) < 0.5:
+        return False
     return pool in (1, 2, 4) and pitch_bytes % 16 == 0 and (pool > 1 or width_out % 16 == 0)
 
 
@@ -496,7 +499,7 @@ def compress_plane(plane, block_size=1, mode="qtable", param=0.0):
     h, w = hh // bs, ww // bs
     nblocks = (h // 8) * (w // 8)
     as_u8 = (src.dtype == np.uint8 or (src.dtype.kind in "ui" and src.size and src.min() >= 0 and src.max() <= 255)) \
-        and u8_path_ok(w, bs, ww)
+        and u8_path_ok(w, bs, ww, mode, param)
     a = np.ascontiguousarray(src, dtype=np.uint8 if as_u8 else np.float32)
     L = lib()
     din, dzz = DeviceBuffer(a.nbytes), DeviceBuffer(h * w * 2)

@@ -59,13 +59,25 @@ class QuantizationMethod:
         return QuantizationMethod(name, **d)
 
     def gpu_mode(self):
-        """(mode name, scalar parameter) understood by libjpegx, or None if not expressible."""
+        """(mode name, scalar parameter) understood by libjpegx, or None if not expressible.  Only the STOCK
+        quantiser objects qualify: a replaced or subclassed quantiser, or an edited luminance table, is a
+        different function and goes through the object's own quantize/restore like in the reference."""
         q = self.quantizer
+        if type(q) is not self.name_to_quantizer.get(self.name):
+            return None
         if self.name == "discard":
             return ("discard", float(q.keep)) if isinstance(q.keep, (int, np.integer)) and q.keep >= 0 else None
         if self.name == "divide":
-            return ("divide", float(q.divisor)) if q.divisor != 0 else None
-        return (self.name, 0.0) if self.name in ("none", "qtable") else None
+            try:
+                d = float(q.divisor)
+            except (TypeError, ValueError):
+                return None
+            return ("divide", d) if d != 0 and np.isfinite(d) else None
+        if self.name == "qtable":
+            stock = np.array(JpegQuantizationTable.table)
+            same = np.array_equal(np.asarray(q.table), stock) and np.array_equal(getattr(q, "_qtable", stock), stock)
+            return ("qtable", 0.0) if same else None
+        return ("none", 0.0) if self.name == "none" else None
 
 
 class Configuration:
@@ -124,6 +136,25 @@ def _stock_registry():
     return len(step_classes) == len(_BUILTIN_STEPS) and all(a is b for a, b in zip(step_classes, _BUILTIN_STEPS))
 
 
+def _hot_run(classes):
+    """Index at which the three built-in hot steps stand directly one after another in ``classes`` (only
+    then may steps 4+5+6 be one launch: a user step registered between them, or a subclass standing in for
+    one of them, must run at its own place in the order, like in the reference), else None."""
+    for i in range(len(classes) - 2):
+        if all(a is b for a, b in zip(classes[i:i + 3], _HOT_STEPS)):
+            return i
+    return None
+
+
+def _bad_rle(exc):
+    """libjpegx reports the reference's BadRleCodeError condition (amplitude beyond 15 bits, illegal code in a
+    stream) in its error text; callers of the pipeline API get the reference's exception type."""
+    import util
+    if "BadRleCodeError" in str(exc):
+        return util.BadRleCodeError(str(exc))
+    return exc
+
+
 def _front_end_fused(band, config, with_entropy):
     """Steps 0-6 (or 0-8 when with_entropy) on the GPU when the band needs no DCT padding: Padding
     on the host (edge replication to a multiple of block_size), then SubSampling + BasisChange +
@@ -175,49 +206,59 @@ def _back_end_fused(zz, config):
 
 def compress_band(a, config):
     """Run every registered step forward (pipeline/__init__.py:71-76)."""
+    import jpegx
     fused = _accelerated(config)
     todo = list(step_classes)
-    if fused and _stock_registry():
-        blob = _front_end_fused(a, config, with_entropy=True)
-        if blob is not None:
-            return blob                               # all nine steps on the device
-    for cls in todo:
-        if fused and cls.step_index in (5, 6) and cls in _HOT_STEPS:
-            continue                                   # folded into the fused launch below
-        if fused and cls is basis_change.BasisChange:
-            a = _hot_forward(a, config)
-            continue
-        a = cls(config).execute(a)
-    return a
+    try:
+        if fused and _stock_registry():
+            blob = _front_end_fused(a, config, with_entropy=True)
+            if blob is not None:
+                return blob                               # all nine steps on the device
+        at = _hot_run(todo) if fused else None
+        for k, cls in enumerate(todo):
+            if at is not None and at < k <= at + 2:
+                continue                                   # folded into the fused launch at `at`
+            if at is not None and k == at:
+                a = _hot_forward(a, config)
+                continue
+            a = cls(config).execute(a)
+        return a
+    except jpegx.JpegxError as exc:
+        raise _bad_rle(exc)
 
 
 def decompress_band(compression_result, config):
     """Run every registered step backwards (pipeline/__init__.py:79-88)."""
+    import jpegx
     a = compression_result
     fused = _accelerated(config)
     todo = list(reversed(step_classes))
-    if fused and _stock_registry():
-        if isinstance(a, (bytes, bytearray)):
-            # entropy stage inverted on the host by libjpegx's C++ parser (steps 8, 7)
-            import jpegx
-            rle = run_length_encoding.RunLengthEncoding(config)
-            hb, wb = rle._height_in_blocks(), rle._width_in_blocks()
-            a = jpegx.entropy_decode(a, hb * wb).reshape(hb, wb, 64)
-        else:
-            for cls in todo[:2]:
-                a = cls(config).invert(a)
-        band = _back_end_fused(a, config)
-        if band is not None:
-            return band
-        todo = todo[2:]
-    for cls in todo:
-        if fused and cls.step_index in (4, 5) and cls in _HOT_STEPS:
-            continue
-        if fused and cls is zigzag_order.ZigzagOrder:
-            a = _hot_inverse(a, config)
-            continue
-        a = cls(config).invert(a)
-    return a
+    try:
+        if fused and _stock_registry():
+            if isinstance(a, (bytes, bytearray)):
+                # entropy stage inverted on the host by libjpegx's C++ parser (steps 8, 7)
+                rle = run_length_encoding.RunLengthEncoding(config)
+                hb, wb = rle._height_in_blocks(), rle._width_in_blocks()
+                a = jpegx.entropy_decode(a, hb * wb).reshape(hb, wb, 64)
+            else:
+                for cls in todo[:2]:
+                    a = cls(config).invert(a)
+            band = _back_end_fused(a, config)
+            if band is not None:
+                return band
+            todo = todo[2:]
+        at = _hot_run(list(reversed(todo))) if fused else None      # position counted in forward order
+        at = None if at is None else len(todo) - 3 - at             # -> index of ZigzagOrder in the reversed list
+        for k, cls in enumerate(todo):
+            if at is not None and at < k <= at + 2:
+                continue
+            if at is not None and k == at:
+                a = _hot_inverse(a, config)
+                continue
+            a = cls(config).invert(a)
+        return a
+    except jpegx.JpegxError as exc:
+        raise _bad_rle(exc)
 
 
 class CompressedData:

@@ -15,19 +15,12 @@ class Quantization(AlgorithmStep):
     step_index = 5
 
     def _gpu_args(self, array):
-        """(mode, param) when the plane can go through libjpegx, else None."""
+        """(mode, param) when the plane can go through libjpegx (stock quantiser objects only), else None."""
         cfg = self._config
-        method = cfg.quantization
         if (cfg.dct_size != 8 or array.ndim != 2 or array.size == 0 or array.shape[0] % 8 or array.shape[1] % 8
-                or array.dtype.kind not in "fiu" or method.name not in _MODES):
+                or array.dtype.kind not in "fiu" or cfg.quantization.name not in _MODES):
             return None
-        if method.name == "discard":
-            keep = method.quantizer.keep
-            return ("discard", float(keep)) if isinstance(keep, (int, np.integer)) and keep >= 0 else None
-        if method.name == "divide":
-            d = method.quantizer.divisor
-            return ("divide", float(d)) if d != 0 else None
-        return method.name, 0.0
+        return cfg.quantization.gpu_mode()
 
     def _run(self, array, gpu_fn, attr):
         array = np.asarray(array)

@@ -143,3 +143,84 @@ def test_decompress_band_fast_path_equals_generic_path(gpu, golden):
     for cls in reversed(step_classes):                   # the reference's plain loop
         a = cls(cfg).invert(a)
     assert np.array_equal(fast, a) and np.array_equal(fast, c["band_qtable"])
+
+
+def _step_by_step(band, cfg, classes):
+    a = band
+    for cls in classes:
+        a = cls(cfg).execute(a)
+    return a
+
+
+def test_user_step_between_the_hot_steps_runs_at_its_place(gpu, golden):
+    """Plugin contract (pipeline/base.py:23-31): a step registered with 4 < step_index < 5 sees the DCT
+    coefficients, not the zigzagged integers -- the three hot steps are then NOT fused.  Compared with
+    executing every registered class one by one; the registry is restored afterwards."""
+    from pipeline.base import AlgorithmStep, step_classes
+    c = golden("noise64")
+    band = c["input"].astype(np.int64)
+    cfg = config_for(c, QuantizationMethod("qtable"))
+    stock = list(step_classes)
+    try:
+        class HalveHighRows(AlgorithmStep):
+            step_index = 4.5
+
+            def execute(self, array):
+                out = np.array(array, dtype=np.float64)
+                out[4::8, :] *= 0.5
+                return out
+
+            def invert(self, array):
+                out = np.array(array, dtype=np.float64)
+                out[4::8, :] *= 2.0
+                return out
+        assert not pipeline._stock_registry() and pipeline._hot_run(list(step_classes)) is None
+        want = _step_by_step(band, cfg, list(step_classes))
+        got = compress_band(band, cfg)
+        assert got == want
+        assert got != _step_by_step(band, cfg, stock)                         # the user step really took part
+        back = decompress_band(got, cfg)
+        a = got
+        for cls in reversed(list(step_classes)):
+            a = cls(cfg).invert(a)
+        assert np.array_equal(back, a)
+    finally:
+        step_classes[:] = stock
+    assert pipeline._stock_registry()
+
+
+def test_edited_quantisation_table_is_honoured(gpu, golden):
+    """A QuantizationMethod whose quantiser object is not the stock one (here: a doubled table) must not be
+    mapped onto the built-in 'qtable' kernel mode: the result follows the object, as in the reference."""
+    c = golden("smooth64")
+    band = c["input"].astype(np.int64)
+    m = QuantizationMethod("qtable")
+    m.quantizer._qtable = m.quantizer._qtable * 2
+    cfg = config_for(c, m)
+    blob = compress_band(band, cfg)
+    zz = RunLengthEncoding(cfg).invert(RleBytestream(cfg).invert(blob))
+    dct = BasisChange(cfg).execute(c["pre"])
+    want = np.round(dct.reshape(8, 8, 8, 8).transpose(0, 2, 1, 3) * (1.0 / m.quantizer._qtable)).transpose(0, 2, 1, 3).reshape(64, 64)
+    assert np.array_equal(ZigzagOrder(cfg).invert(zz), want)
+    assert not np.array_equal(zz, c["zz_qtable"])
+
+
+def test_amplitudes_beyond_15_bits_raise_the_reference_exception(gpu):
+    """divide with a tiny divisor on an 8-bit band: DC / 0.01 needs more than 15 bits.  The reference raises
+    util.BadRleCodeError from step 7; so do the fused path (uint8 and fp32 input) and the step-by-step path."""
+    import util
+    band = np.full((16, 32), 255, dtype=np.int64)
+    for bs in (1, 2):
+        cfg = Configuration(width=32, height=16, block_size=bs, quantization=QuantizationMethod("divide", divisor=0.01))
+        with pytest.raises(util.BadRleCodeError):
+            compress_band(band, cfg)
+    cfg = Configuration(width=32, height=16, block_size=1, quantization=QuantizationMethod("divide", divisor=0.01))
+    with pytest.raises(util.BadRleCodeError):
+        _step_by_step(band, cfg, pipeline._BUILTIN_STEPS)
+    # the raw kernels saturate instead of wrapping around
+    zz = gpu.forward_fused(band.astype(np.float32), "divide", 0.01)
+    assert zz[0, 0, 0] == 32767
+    with pytest.raises(gpu.JpegxError):
+        gpu.forward_fused_u8(band.astype(np.uint8), 1, "divide", 0.01)
+    with pytest.raises(util.BadRleCodeError):
+        decompress_band(b"\x30\x00", cfg)                    # run 3 with size 0: not a legal code

@@ -275,3 +275,50 @@ def test_host_entropy_decoder_inverts_the_python_encoder(golden):
     for bad in (b"", b"\x12", b"\xf0\xf0\xf0\xf0\xf0\x00"):
         with pytest.raises(jpegx.JpegxError):
             jpegx.entropy_decode(bad, 1)
+
+
+# ---- when the three hot steps may be fused (plugin contract, pipeline/base.py:23-31) -----------
+def test_hot_steps_fuse_only_when_adjacent_and_stock():
+    from pipeline import _hot_run, _HOT_STEPS, _BUILTIN_STEPS
+    from pipeline.basis_change import BasisChange
+    from pipeline.quantization import Quantization
+    assert _hot_run(list(_BUILTIN_STEPS)) == 4
+
+    class Between:           # stands for a user step registered with 4 < step_index < 5
+        step_index = 4.5
+
+    class MyQuantization(Quantization):
+        step_index = 5
+    steps = list(_BUILTIN_STEPS)
+    assert _hot_run(steps[:5] + [Between] + steps[5:]) is None
+    assert _hot_run(steps[:5] + [MyQuantization] + steps[6:]) is None          # a subclass is not the built-in step
+    assert _hot_run([BasisChange] + list(_HOT_STEPS)) == 1
+    assert _hot_run(list(_HOT_STEPS[:2])) is None
+    # the registry itself is untouched by these local classes only because they do not derive from AlgorithmStep
+    # through the metaclass... MyQuantization does: take it out again
+    pipeline.step_classes.remove(MyQuantization)
+    assert pipeline._stock_registry()
+
+
+def test_gpu_mode_accepts_stock_quantiser_objects_only():
+    import quantizers
+    assert QuantizationMethod("qtable").gpu_mode() == ("qtable", 0.0)
+    assert QuantizationMethod("none").gpu_mode() == ("none", 0.0)
+    assert QuantizationMethod("divide", divisor=40).gpu_mode() == ("divide", 40.0)
+    assert QuantizationMethod("discard", keep=3).gpu_mode() == ("discard", 3.0)
+    assert QuantizationMethod("divide", divisor=0).gpu_mode() is None
+    m = QuantizationMethod("qtable")
+    m.quantizer._qtable = m.quantizer._qtable * 2                 # an edited table is a different quantiser
+    assert m.gpu_mode() is None
+    m = QuantizationMethod("qtable")
+    m.quantizer.table = [[1] * 8] * 8
+    assert m.gpu_mode() is None
+
+    class Mine(quantizers.DivisionQuantizer):
+        def quantize(self, a):
+            return np.floor(a / self.divisor)
+    m = QuantizationMethod("divide", divisor=7)
+    m.quantizer = Mine(7)
+    assert m.gpu_mode() is None
+    cfg = Configuration(width=8, height=8, block_size=1, quantization=m)
+    assert not pipeline._accelerated(cfg)                          # everything then runs step by step on the host objects
