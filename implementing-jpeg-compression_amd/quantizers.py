@@ -25,7 +25,7 @@ class RoundingQuantizer:
 
     def quantize(self, a):
         a = np.asarray(a)
-        if _gpu_eligible(a):
+        if type(self) is RoundingQuantizer and _gpu_eligible(a):
             return _on_gpu("quantize_f64", a, "none", 0.0)
         return np.round(a)
 
@@ -41,7 +41,8 @@ class DiscardingQuantizer(RoundingQuantizer):
 
     def quantize(self, a):
         a = np.asarray(a)
-        if a.shape == (8, 8) and _gpu_eligible(a) and isinstance(self.keep, (int, np.integer)) and self.keep >= 0:
+        if type(self) is DiscardingQuantizer and a.shape == (8, 8) and _gpu_eligible(a) and \
+                isinstance(self.keep, (int, np.integer)) and self.keep >= 0:
             return _on_gpu("quantize_f64", a, "discard", float(self.keep))
         out = np.round(a)
         out[self.keep:] = 0
@@ -57,7 +58,7 @@ class DivisionQuantizer(RoundingQuantizer):
 
     def quantize(self, a):
         a = np.asarray(a)
-        if _gpu_eligible(a) and self.divisor != 0:
+        if type(self) is DivisionQuantizer and _gpu_eligible(a) and self.divisor != 0:
             return _on_gpu("quantize_f64", a, "divide", float(self.divisor))
         return np.round(a / float(self.divisor))
 
@@ -79,14 +80,19 @@ class JpegQuantizationTable(RoundingQuantizer):
     def __init__(self):
         self._qtable = np.array(self.table)
 
+    def _stock(self):
+        """The device kernels hold the standard table: an edited one stays on the host."""
+        return type(self) is JpegQuantizationTable and self._qtable.shape == (8, 8) and \
+            np.array_equal(self._qtable.ravel(), _LUMINANCE)
+
     def quantize(self, a):
         a = np.asarray(a)
-        if a.shape == (8, 8) and _gpu_eligible(a):
+        if a.shape == (8, 8) and _gpu_eligible(a) and self._stock():
             return _on_gpu("quantize_f64", a, "qtable", 0.0)
         return np.round(a * (1.0 / self._qtable))
 
     def restore(self, a):
         a = np.asarray(a)
-        if a.shape == (8, 8) and _gpu_eligible(a):
+        if a.shape == (8, 8) and _gpu_eligible(a) and self._stock():
             return _on_gpu("restore_f64", a, "qtable", 0.0)
         return np.round(a * self._qtable)
