@@ -1,0 +1,252 @@
+// jpegx_hostpipe.cpp -- the host-pointer side of libjpegx.so done natively: per-device pools of
+// device buffers, a stream and pinned staging memory (grow-only, reused across calls instead of a
+// hipMalloc + hipStreamCreate per call), and the whole compress_band job for one plane
+// (range check + narrowing of wide integer bands, upload, fused forward, device entropy stage,
+// download straight into the caller's bytes) in two C calls.
+//
+// Replaces, for 8-bit bands with transform 'DCT' / dct_size 8, the loop of pipeline/__init__.py:71-76
+// of the reference (steps 1..8 on one band; step 0 padding stays with the caller).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <atomic>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#include "../../include/jpegx.h"
+
+extern "C" void jpegx_internal_set_error(const char *msg);
+
+namespace {
+
+int fail(int code, const char *msg)
+{
+    jpegx_internal_set_error(msg);
+    return code;
+}
+
+#define HP_TRY(expr)                                                                        \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess) {                                                             \
+            char buf_[400];                                                                 \
+            snprintf(buf_, sizeof(buf_), "%s failed: %s", #expr, hipGetErrorString(e_));    \
+            jpegx_internal_set_error(buf_);                                                 \
+            return JPEGX_E_HIP;                                                             \
+        }                                                                                   \
+    } while (0)
+
+// a grow-only allocation (device or pinned host)
+struct Span {
+    void *p = nullptr;
+    size_t cap = 0;
+    bool pinned = false;
+    int ensure(size_t bytes)
+    {
+        if (bytes <= cap) return JPEGX_OK;
+        if (p) {
+            if (pinned) (void)hipHostFree(p); else (void)hipFree(p);
+            p = nullptr;
+            cap = 0;
+        }
+        const size_t want = bytes + bytes / 8 + 4096;          // head room: similar bands follow
+        if (pinned) HP_TRY(hipHostMalloc(&p, want, hipHostMallocDefault)); else HP_TRY(hipMalloc(&p, want));
+        cap = want;
+        return JPEGX_OK;
+    }
+};
+
+constexpr int MAX_DEVICES = 16;
+
+struct DevicePool {
+    std::mutex mu;                // one host job at a time per device
+    hipStream_t stream = nullptr;
+    Span d_in, d_zz, d_ws, d_out;
+    Span h_in{nullptr, 0, true};
+    // state between jpegx_host_compress_begin and _finish (the pool stays locked in between)
+    bool open = false;
+    size_t out_bytes = 0;
+    std::thread::id owner;
+};
+
+DevicePool g_pool[MAX_DEVICES];
+
+int current_pool(DevicePool **pool)
+{
+    int dev = 0;
+    HP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= MAX_DEVICES) return fail(JPEGX_E_UNSUPPORTED, "device index beyond the pool table");
+    *pool = &g_pool[dev];
+    return JPEGX_OK;
+}
+
+// wide integers -> bytes, checking 0..255 on the way, split over a few host threads (a 4096^2 int64 band is
+// 128 MiB: one core needs ~13 ms for it, eight need ~2)
+template <typename T>
+bool narrow_rows(const T *src, ptrdiff_t src_pitch, int H, int W, uint8_t *dst, ptrdiff_t dst_pitch)
+{
+    const unsigned hw = std::thread::hardware_concurrency();
+    const int nthreads = (int)(((size_t)H * W < (1u << 20)) ? 1 : (hw >= 8 ? 8 : (hw ? hw : 1)));
+    std::atomic<bool> ok{true};
+    auto work = [&](int y0, int y1) {
+        bool good = true;
+        for (int y = y0; y < y1; ++y) {
+            const T *s = src + (size_t)y * src_pitch;
+            uint8_t *d = dst + (size_t)y * dst_pitch;
+            T seen = 0;
+            for (int x = 0; x < W; ++x) {
+                seen |= s[x];
+                d[x] = (uint8_t)s[x];
+            }
+            if (seen & ~(T)0xFF) good = false;               // a negative value or one above 255 in this row
+        }
+        if (!good) ok = false;
+    };
+    if (nthreads == 1) {
+        work(0, H);
+    } else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < nthreads; ++t) th.emplace_back(work, (int)((long long)H * t / nthreads), (int)((long long)H * (t + 1) / nthreads));
+        for (auto &t : th) t.join();
+    }
+    return ok;
+}
+
+}  // namespace
+
+extern "C" {
+
+int jpegx_host_compress_begin(const void *h_plane, int elem_size, int H, int W, ptrdiff_t pitch, int bs, int mode,
+                              double param, size_t *nbytes)
+{
+    if (!h_plane || !nbytes) return fail(JPEGX_E_INVALID, "null pointer");
+    if (bs != 1 && bs != 2 && bs != 4) return fail(JPEGX_E_UNSUPPORTED, "host_compress supports block_size 1, 2 and 4");
+    if (H <= 0 || W <= 0 || (H % 8) || (W % 8)) return fail(JPEGX_E_INVALID, "plane height and width (after pooling) must be positive multiples of 8");
+    if (elem_size != 1 && elem_size != 4 && elem_size != 8) return fail(JPEGX_E_UNSUPPORTED, "host_compress takes uint8, int32 or int64 samples");
+    const int HH = H * bs, WW = W * bs;
+    if (pitch < WW) return fail(JPEGX_E_INVALID, "pitch smaller than the row");
+    if ((WW % 16) != 0) return fail(JPEGX_E_UNSUPPORTED, "host_compress needs rows of a multiple of 16 samples");
+    DevicePool *pool = nullptr;
+    int rc = current_pool(&pool);
+    if (rc) return rc;
+    pool->mu.lock();
+    auto bail = [&](int code) { pool->mu.unlock(); return code; };
+    if (!pool->stream && hipStreamCreateWithFlags(&pool->stream, hipStreamNonBlocking) != hipSuccess)
+        return bail(fail(JPEGX_E_HIP, "hipStreamCreate failed"));
+    const size_t in_bytes = (size_t)HH * WW;
+    const long long nblocks = (long long)(H / 8) * (W / 8);
+    if ((rc = pool->d_in.ensure(in_bytes)) || (rc = pool->d_zz.ensure((size_t)nblocks * 128)) ||
+        (rc = pool->d_ws.ensure(jpegx_entropy_workspace_bytes(nblocks))))
+        return bail(rc);
+    hipStream_t st = pool->stream;
+    const uint8_t *src8 = static_cast<const uint8_t *>(h_plane);
+    ptrdiff_t src_pitch = pitch;
+    if (elem_size != 1) {
+        if ((rc = pool->h_in.ensure(in_bytes))) return bail(rc);
+        const bool ok = elem_size == 8
+            ? narrow_rows(static_cast<const int64_t *>(h_plane), pitch, HH, WW, static_cast<uint8_t *>(pool->h_in.p), WW)
+            : narrow_rows(static_cast<const int32_t *>(h_plane), pitch, HH, WW, static_cast<uint8_t *>(pool->h_in.p), WW);
+        if (!ok) return bail(fail(JPEGX_E_UNSUPPORTED, "samples outside 0..255: not an 8-bit band"));
+        src8 = static_cast<const uint8_t *>(pool->h_in.p);
+        src_pitch = WW;
+    }
+    hipError_t e = (src_pitch == WW)
+        ? hipMemcpyAsync(pool->d_in.p, src8, in_bytes, hipMemcpyHostToDevice, st)
+        : hipMemcpy2DAsync(pool->d_in.p, WW, src8, (size_t)src_pitch, WW, HH, hipMemcpyHostToDevice, st);
+    if (e != hipSuccess) return bail(fail(JPEGX_E_HIP, "host to device copy failed"));
+    if ((rc = jpegx_forward_fused_u8(static_cast<const uint8_t *>(pool->d_in.p), H, W, WW, bs, mode, param, 0,
+                                     static_cast<int16_t *>(pool->d_zz.p), st)) ||
+        (rc = jpegx_entropy_sizes(static_cast<const int16_t *>(pool->d_zz.p), nblocks, pool->d_ws.p, st)))
+        return bail(rc);
+    unsigned long long total = 0;
+    if ((rc = jpegx_entropy_total(pool->d_ws.p, &total, st))) return bail(rc);      // synchronises
+    if ((rc = pool->d_out.ensure(total ? (size_t)total : 1))) return bail(rc);
+    if ((rc = jpegx_entropy_emit(static_cast<const int16_t *>(pool->d_zz.p), nblocks, pool->d_ws.p,
+                                 static_cast<uint8_t *>(pool->d_out.p), st)))
+        return bail(rc);
+    pool->open = true;
+    pool->out_bytes = (size_t)total;
+    pool->owner = std::this_thread::get_id();
+    *nbytes = (size_t)total;
+    return JPEGX_OK;                       // the pool stays locked until _finish / _abort
+}
+
+int jpegx_host_compress_finish(uint8_t *h_out)
+{
+    DevicePool *pool = nullptr;
+    int rc = current_pool(&pool);
+    if (rc) return rc;
+    if (!pool->open || pool->owner != std::this_thread::get_id()) return fail(JPEGX_E_INVALID, "no open compress job on this thread and device");
+    hipError_t e = hipSuccess;
+    if (pool->out_bytes) {
+        if (!h_out) e = hipErrorInvalidValue;
+        if (e == hipSuccess) e = hipMemcpyAsync(h_out, pool->d_out.p, pool->out_bytes, hipMemcpyDeviceToHost, pool->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(pool->stream);
+    pool->open = false;
+    pool->mu.unlock();
+    if (e != hipSuccess) return fail(JPEGX_E_HIP, "device to host copy failed");
+    return JPEGX_OK;
+}
+
+int jpegx_host_compress_abort(void)
+{
+    DevicePool *pool = nullptr;
+    int rc = current_pool(&pool);
+    if (rc) return rc;
+    if (pool->open && pool->owner == std::this_thread::get_id()) {
+        (void)hipStreamSynchronize(pool->stream);
+        pool->open = false;
+        pool->mu.unlock();
+    }
+    return JPEGX_OK;
+}
+
+// used by host_roundtrip (jpegx_internal.h): the synchronous host-pointer conveniences borrow the pool's
+// stream and its input / output device spans for the duration of one call; not part of the public ABI
+int jpegx_internal_pool_acquire(size_t in_bytes, size_t out_bytes, void **d_in, void **d_out, void **stream)
+{
+    DevicePool *pool = nullptr;
+    int rc = current_pool(&pool);
+    if (rc) return rc;
+    pool->mu.lock();
+    if (!pool->stream && hipStreamCreateWithFlags(&pool->stream, hipStreamNonBlocking) != hipSuccess) {
+        pool->mu.unlock();
+        return fail(JPEGX_E_HIP, "hipStreamCreate failed");
+    }
+    if ((rc = pool->d_in.ensure(in_bytes ? in_bytes : 1)) || (rc = pool->d_out.ensure(out_bytes ? out_bytes : 1))) {
+        pool->mu.unlock();
+        return rc;
+    }
+    *d_in = pool->d_in.p;
+    *d_out = pool->d_out.p;
+    *stream = pool->stream;
+    return JPEGX_OK;
+}
+
+void jpegx_internal_pool_release(void)
+{
+    DevicePool *pool = nullptr;
+    if (current_pool(&pool) == JPEGX_OK) pool->mu.unlock();
+}
+
+// release everything the pools hold on the current device (tests; long-lived processes that are done)
+int jpegx_host_pool_release(void)
+{
+    DevicePool *pool = nullptr;
+    int rc = current_pool(&pool);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lock(pool->mu);
+    for (Span *s : {&pool->d_in, &pool->d_zz, &pool->d_ws, &pool->d_out, &pool->h_in}) {
+        if (s->p) { if (s->pinned) (void)hipHostFree(s->p); else (void)hipFree(s->p); }
+        s->p = nullptr;
+        s->cap = 0;
+    }
+    if (pool->stream) { (void)hipStreamDestroy(pool->stream); pool->stream = nullptr; }
+    return JPEGX_OK;
+}
+
+}  // extern "C"

@@ -106,30 +106,30 @@ int fill_inverse_params(int mode, double param, QuantParams *qp)
     }
 }
 
-struct DevBuf {
-    void *p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    int alloc(size_t bytes) { HIP_TRY(hipMalloc(&p, bytes ? bytes : 1)); return JPEGX_OK; }
-};
-struct Stream {
-    hipStream_t s = nullptr;
-    ~Stream() { if (s) (void)hipStreamDestroy(s); }
-    int create() { HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking)); return JPEGX_OK; }
-};
+extern "C" int jpegx_internal_pool_acquire(size_t in_bytes, size_t out_bytes, void **d_in, void **d_out, void **stream);
+extern "C" void jpegx_internal_pool_release(void);
 
-// generic "copy in, run, copy out" helper
+// generic "copy in, run, copy out" helper on the device's pooled stream and buffers (jpegx_hostpipe.cpp):
+// no hipMalloc / hipStreamCreate per call once the pool has grown to the working size
 template <typename F>
 int host_roundtrip(const void *h_in, size_t in_bytes, void *h_out, size_t out_bytes, F &&run)
 {
     if (!h_in || !h_out) return fail(JPEGX_E_INVALID, "null host pointer");
-    DevBuf din, dout;
-    Stream st;
-    int rc;
-    if ((rc = din.alloc(in_bytes)) || (rc = dout.alloc(out_bytes)) || (rc = st.create())) return rc;
-    HIP_TRY(hipMemcpyAsync(din.p, h_in, in_bytes, hipMemcpyHostToDevice, st.s));
-    if ((rc = run(din.p, dout.p, (jpegx_stream_t)st.s))) return rc;
-    HIP_TRY(hipMemcpyAsync(h_out, dout.p, out_bytes, hipMemcpyDeviceToHost, st.s));
-    HIP_TRY(hipStreamSynchronize(st.s));
+    void *din = nullptr, *dout = nullptr, *st = nullptr;
+    int rc = jpegx_internal_pool_acquire(in_bytes, out_bytes, &din, &dout, &st);
+    if (rc) return rc;
+    hipError_t e = hipMemcpyAsync(din, h_in, in_bytes, hipMemcpyHostToDevice, (hipStream_t)st);
+    if (e == hipSuccess) {
+        rc = run(din, dout, (jpegx_stream_t)st);
+        if (rc == JPEGX_OK) e = hipMemcpyAsync(h_out, dout, out_bytes, hipMemcpyDeviceToHost, (hipStream_t)st);
+    }
+    const hipError_t e2 = hipStreamSynchronize((hipStream_t)st);
+    jpegx_internal_pool_release();
+    if (rc) return rc;
+    if (e != hipSuccess || e2 != hipSuccess) {
+        snprintf(g_err, sizeof(g_err), "host round trip failed: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+        return JPEGX_E_HIP;
+    }
     return JPEGX_OK;
 }
 

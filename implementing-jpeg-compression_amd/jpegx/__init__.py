@@ -93,6 +93,10 @@ SIGNATURES = {
     "jpegx_host_dct8x8_f32": [_vp, _int, _int, _vp],
     "jpegx_host_idct8x8_f32": [_vp, _int, _int, _vp],
     "jpegx_set_debug_counters": [_vp],
+    "jpegx_host_compress_begin": [_vp, _int, _int, _int, _pd, _int, _int, _dbl, _c.POINTER(_sz)],
+    "jpegx_host_compress_finish": [_vp],
+    "jpegx_host_compress_abort": [],
+    "jpegx_host_pool_release": [],
     "jpegx_entropy_workspace_bytes": [_c.c_longlong],
     "jpegx_entropy_sizes": [_vp, _c.c_longlong, _vp, _vp],
     "jpegx_entropy_total": [_vp, _c.POINTER(_c.c_ulonglong), _vp],
@@ -486,6 +490,44 @@ def entropy_block_sizes(zz):
         dws.free()
 
 
+_ELEM_OF = {np.dtype(np.uint8): 1, np.dtype(np.int32): 4, np.dtype(np.int64): 8}
+_pyapi = ctypes.pythonapi
+_pyapi.PyBytes_FromStringAndSize.restype = ctypes.py_object
+_pyapi.PyBytes_FromStringAndSize.argtypes = [ctypes.c_void_p, ctypes.c_ssize_t]
+_pyapi.PyBytes_AsString.restype = ctypes.c_void_p
+_pyapi.PyBytes_AsString.argtypes = [ctypes.py_object]
+
+
+def compress_plane_native(plane, block_size=1, mode="qtable", param=0.0):
+    """compress_plane through libjpegx's native host pipeline (jpegx_host_compress_begin / _finish): pooled
+    device buffers and stream, range check + narrowing of int32 / int64 bands in native threads, and the
+    byte stream copied from the device straight into the returned ``bytes`` object.  Returns None when the
+    plane is not an 8-bit band in a layout that path takes (the caller then uses compress_plane)."""
+    src = plane if isinstance(plane, np.ndarray) else np.asarray(plane)
+    bs = int(block_size)
+    elem = _ELEM_OF.get(src.dtype)
+    if elem is None or src.ndim != 2 or not src.flags.c_contiguous:
+        return None
+    hh, ww = src.shape
+    if hh == 0 or hh % (8 * bs) or ww % (8 * bs) or ww % 16 or not u8_path_ok(ww // bs, bs, ww, mode, param):
+        return None
+    L = lib()
+    n = ctypes.c_size_t(0)
+    rc = L.jpegx_host_compress_begin(src.ctypes.data, elem, hh // bs, ww // bs, ww, bs, mode_of(mode), float(param),
+                                     ctypes.byref(n))
+    if rc == -4:                                        # JPEGX_E_UNSUPPORTED: not an 8-bit band after all
+        return None
+    check(rc, "jpegx_host_compress_begin")
+    try:
+        blob = _pyapi.PyBytes_FromStringAndSize(None, n.value)      # uninitialised bytes, filled below
+        rc = L.jpegx_host_compress_finish(_pyapi.PyBytes_AsString(blob))
+    except BaseException:
+        L.jpegx_host_compress_abort()
+        raise
+    check(rc, "jpegx_host_compress_finish")
+    return blob
+
+
 def compress_plane(plane, block_size=1, mode="qtable", param=0.0):
     """Steps 1-8 of the codec for one (already padded) plane with everything on the device:
     fused mean-pool + DCT + quantise + zigzag, then the entropy stage; only the final bytes come back."""
@@ -496,6 +538,9 @@ def compress_plane(plane, block_size=1, mode="qtable", param=0.0):
     hh, ww = src.shape
     if hh % (8 * bs) or ww % (8 * bs):
         raise JpegxError("plane must be a multiple of 8*block_size in both dimensions")
+    blob = compress_plane_native(src, bs, mode, param)
+    if blob is not None:
+        return blob
     h, w = hh // bs, ww // bs
     nblocks = (h // 8) * (w // 8)
     as_u8 = (src.dtype == np.uint8 or (src.dtype.kind in "ui" and src.size and src.min() >= 0 and src.max() <= 255)) \

@@ -165,11 +165,16 @@ def _front_end_fused(band, config, with_entropy):
     band = np.asarray(band)
     if bs not in (1, 2, 4) or band.ndim != 2 or band.size == 0 or band.dtype.kind not in "ui":
         return None
-    if band.min() < 0 or band.max() > 255:
-        return None
-    padded = band if bs == 1 else padding.Padding(config).execute(band)
     import jpegx
     mode, param = config.quantization.gpu_mode()
+    padded = band if bs == 1 else padding.Padding(config).execute(band)
+    if with_entropy and not (padded.shape[0] % (8 * bs) or padded.shape[1] % (8 * bs)):
+        # the common case in one native call: range check, upload, steps 1+4..8, bytes back
+        blob = jpegx.compress_plane_native(np.ascontiguousarray(padded), bs, mode, param)
+        if blob is not None:
+            return blob
+    if band.dtype != np.uint8 and (band.min() < 0 or band.max() > 255):
+        return None
     if padded.shape[0] % (8 * bs) or padded.shape[1] % (8 * bs):
         # DCT padding is needed: it replicates POOLED edge samples (dct_padding.py:8-9), so pool on
         # the host first (steps 1-3), then the device does steps 4-8 on the padded plane

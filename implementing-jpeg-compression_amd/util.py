@@ -64,8 +64,12 @@ def split_into_blocks(a, block_size):
 
 
 def band_to_array(band):
-    """PIL band -> (height, width) integer array (util.py:110-112)."""
-    return np.asarray(band, dtype=np.int64).reshape((band.height, band.width))
+    """PIL band -> (height, width) integer array (util.py:110-112).  8-bit bands stay uint8 (the reference
+    builds an int64 array from a Python list; same values, an eighth of the bytes to check and upload)."""
+    a = np.asarray(band)
+    if a.dtype != np.uint8:
+        a = a.astype(np.int64)
+    return a.reshape((band.height, band.width))
 
 
 class Bits:

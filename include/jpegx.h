@@ -249,6 +249,20 @@ int jpegx_host_unzigzag(const void *h_in, int H, int W, int elem_size, void *h_o
 int jpegx_host_dct8x8_f32(const float *h_in, int H, int W, float *h_out);
 int jpegx_host_idct8x8_f32(const float *h_in, int H, int W, float *h_out);
 
+/* ---- one band of compress_band, natively (pipeline/__init__.py:71-76 for transform 'DCT', dct_size 8) -----
+ * h_plane: [H*bs][pitch] samples of elem_size 1 (uint8), 4 (int32) or 8 (int64) bytes -- the dtype
+ * util.band_to_array hands over (util.py:110-112); wide integers are range-checked (0..255, else
+ * JPEGX_E_UNSUPPORTED) and narrowed by a few host threads.  _begin uploads, runs steps 1+4+5+6 (fused) and
+ * 7+8 (device entropy stage) on the device's pooled stream and buffers, and reports the size of the byte
+ * stream; _finish copies it into h_out (>= that many bytes).  Between the two calls the device's pool is
+ * held by the calling thread; _abort gives it back without copying.  W*bs must be a multiple of 16.      */
+int jpegx_host_compress_begin(const void *h_plane, int elem_size, int H, int W, ptrdiff_t pitch, int bs,
+                              int mode, double param, size_t *nbytes);
+int jpegx_host_compress_finish(uint8_t *h_out);
+int jpegx_host_compress_abort(void);
+/* frees the pooled device / pinned buffers and the pooled stream of the current device */
+int jpegx_host_pool_release(void);
+
 /* ---- instrumentation ---------------------------------------------------------------------
  * When d_counters is non-NULL the fused kernels atomically add, per launch:
  * [0] blocks that took the float64 exact tier, [1] blocks processed.  Pass NULL (default) in

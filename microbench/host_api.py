@@ -26,17 +26,18 @@ def main():
     jpegx.require_device()
     size = 4096
     for kind in ("smooth", "noise"):
-        band = jpegx.synth.generate_plane(kind, size, size, seed=1, dtype=np.int64)
-        for bs in (1, 2, 4):
+        band64 = jpegx.synth.generate_plane(kind, size, size, seed=1, dtype=np.int64)
+        for bs, band in ((1, band64.astype(np.uint8)), (1, band64), (2, band64.astype(np.uint8)), (2, band64),
+                         (4, band64.astype(np.uint8))):
             cfg = pipeline.Configuration(width=size, height=size, block_size=bs, dct_size=8,
                                          quantization=pipeline.QuantizationMethod("qtable"))
             pipeline.compress_band(band, cfg)                      # warm-up (allocations, clocks)
             tc, blob = best(lambda: pipeline.compress_band(band, cfg))
             td, rec = best(lambda: pipeline.decompress_band(blob, cfg))
             nblk = (size // bs // 8) ** 2
-            err = float(np.abs(rec - band).mean())
-            print("%-6s block_size %d: compress_band %.1f ms (%.1f Mblocks/s, %d bytes), decompress_band %.1f ms, "
-                  "mean abs error %.2f" % (kind, bs, tc * 1e3, nblk / tc / 1e6, len(blob), td * 1e3, err), flush=True)
+            err = float(np.abs(rec - band64).mean())
+            print("%-6s %-6s block_size %d: compress_band %.2f ms (%.1f Mblocks/s, %d bytes), decompress_band %.1f ms, "
+                  "mean abs error %.2f" % (kind, band.dtype, bs, tc * 1e3, nblk / tc / 1e6, len(blob), td * 1e3, err), flush=True)
 
 
 if __name__ == "__main__":
