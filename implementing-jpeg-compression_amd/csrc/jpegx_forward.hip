@@ -463,6 +463,59 @@ __global__ __launch_bounds__(64) void k_forward_fused_strip_f64(const float *__r
 }
 
 // ------------------------------------------------------------------------------------------------
+// fused forward on a FLOAT64 plane: what step 4 receives when the samples are not exact in fp32 -- the
+// means of SubSampling with block_size 3, 5, 6 ... (pipeline/subsampling.py:9-11: k/9, k/25 ...) or any
+// float64 band a caller passes to BasisChange.  Lane-per-block, everything in float64 in the reference's
+// operation order (transforms.py:46-58 via jpegx_dot8_ref): row pass in place, then per output column
+// the column pass, the reference's own quantiser (quantizers.py:4-49) and the zigzag packing.
+// ------------------------------------------------------------------------------------------------
+template <bool NT>
+__global__ __launch_bounds__(64) void k_forward_fused_f64in(const double *__restrict__ in, size_t pitch, int wb, int nblk,
+                                                            QuantParams prm, int16_t *__restrict__ out,
+                                                            unsigned long long *counters)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char lds[TILE_BYTES];
+    const int lane = threadIdx.x;
+    const int g0 = blockIdx.x * 64;
+    const int gb = min(g0 + lane, nblk - 1);
+    const int by = gb / wb, bx = gb - by * wb;
+    const double *src = in + (size_t)by * 8 * pitch + (size_t)bx * 8;
+    double a[64];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        double x[8];
+#pragma unroll
+        for (int n = 0; n < 8; n += 2) {
+            const double2 t = *reinterpret_cast<const double2 *>(src + (size_t)i * pitch + n);
+            x[n] = t.x; x[n + 1] = t.y;
+        }
+#pragma unroll
+        for (int l = 0; l < 8; ++l) a[i * 8 + l] = jpegx_dot8_ref(&c_dct[l * 8], x, 1);      // M[i][l] = C[l] . A[i]
+    }
+    unsigned pk[32];
+#pragma unroll
+    for (int w = 0; w < 32; ++w) pk[w] = 0u;
+#pragma unroll
+    for (int l = 0; l < 8; ++l) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int n = k * 8 + l;
+            const double y = jpegx_dot8_ref(&c_dct[k * 8], &a[l], 8);                          // Y[k][l] = C[k] . M[:, l]
+            const int q = jpegx_clamp_i16(jpegx_quant_ref(y, n, prm.mode, prm.param, c_rq64.v));
+            constexpr I64 zi = make_zzinv();
+            const int p = zi.v[n];
+            pk[p >> 1] |= ((unsigned)q & 0xFFFFu) << (16 * (p & 1));
+        }
+    }
+    census(counters, 0ull, nblk - g0, lane);
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+        *reinterpret_cast<u32x4 *>(lds + tile_off(lane, c)) = u32x4{pk[c * 4 + 0], pk[c * 4 + 1], pk[c * 4 + 2], pk[c * 4 + 3]};
+    __syncthreads();
+    store_tile<NT>(lds, out, g0, nblk, lane);
+}
+
+// ------------------------------------------------------------------------------------------------
 // fused forward on uint8 planes (the form in which image bands actually arrive: util.band_to_array,
 // util.py:110-112).  64 B (BS=1) or 256 B (BS=2, SubSampling 2x2 mean fused) are read per block
 // instead of 256 B / 1 KiB of fp32, which matters twice: the kernel's HBM traffic drops to 192 B per
@@ -895,6 +948,26 @@ int jpegx_forward_fused_planes(const jpegx_plane_desc *planes, int nplanes, int 
     return JPEGX_OK;
 }
 
+int jpegx_forward_fused_f64(const double *d_in, int H, int W, ptrdiff_t pitch, int mode, double param, unsigned flags,
+                            int16_t *d_out, jpegx_stream_t stream)
+{
+    int rc = check_plane(d_in, d_out, H, W, pitch, 1);
+    if (rc) return rc;
+    if ((pitch % 2) != 0 || !aligned16(d_in) || !aligned16(d_out))
+        return fail(JPEGX_E_INVALID, "forward_f64: pitch must be even (16-byte rows); pointers 16-byte aligned");
+    QuantParams qp;
+    rc = fill_forward_params(mode, param, &qp);
+    if (rc) return rc;
+    const int wb = W / 8, nblk = (H / 8) * wb;
+    const dim3 grid((nblk + 63) / 64), block(64);
+    if (flags & JPEGX_F_TUNE_NO_NT)
+        hipLaunchKernelGGL((k_forward_fused_f64in<false>), grid, block, 0, (hipStream_t)stream, d_in, (size_t)pitch, wb, nblk, qp, d_out, g_counters);
+    else
+        hipLaunchKernelGGL((k_forward_fused_f64in<true>), grid, block, 0, (hipStream_t)stream, d_in, (size_t)pitch, wb, nblk, qp, d_out, g_counters);
+    HIP_TRY(hipGetLastError());
+    return JPEGX_OK;
+}
+
 int jpegx_forward_fused(const float *d_in, int H, int W, ptrdiff_t pitch, int mode, double param, unsigned flags,
                         int16_t *d_out, jpegx_stream_t stream)
 {
@@ -930,6 +1003,13 @@ int jpegx_forward_fused_u8(const uint8_t *d_in, int H, int W, ptrdiff_t pitch, i
 #undef JPEGX_LU8
     HIP_TRY(hipGetLastError());
     return JPEGX_OK;
+}
+int jpegx_host_forward_fused_f64(const double *h_in, int H, int W, int mode, double param, unsigned flags, int16_t *h_out)
+{
+    if (H <= 0 || W <= 0) return fail(JPEGX_E_INVALID, "bad plane shape");
+    return host_roundtrip(h_in, (size_t)H * W * 8, h_out, (size_t)H * W * 2, [&](void *di, void *dout, jpegx_stream_t s) {
+        return jpegx_forward_fused_f64((const double *)di, H, W, W, mode, param, flags, (int16_t *)dout, s);
+    });
 }
 int jpegx_host_forward_fused(const float *h_in, int H, int W, ptrdiff_t pitch, int mode, double param, unsigned flags,
                              int16_t *h_out)

@@ -7,6 +7,7 @@
 #include <stddef.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <string.h>
 
 #include "../../include/jpegx.h"
 
@@ -14,37 +15,31 @@ extern "C" void jpegx_internal_set_error(const char *msg);
 
 namespace {
 
-// MSB-first bit reader over the byte stream with a 64-bit window (refilled a byte at a time)
-struct BitReader {
+// MSB-first view of the byte stream at an arbitrary bit position: peek() returns the next 64 bits
+// left-aligned (at least 57 of them valid), enough for a whole code (8 header + at most 15 amplitude bits)
+// without a refill loop.  Reads beyond the end of the buffer are served from a zero-padded copy of the tail.
+struct BitCursor {
     const uint8_t *p;
-    size_t nbytes, next = 0;       // next byte to load into the window
-    uint64_t window = 0;           // the upcoming bits, left-aligned
-    int have = 0;                  // valid bits in the window
+    size_t nbytes;
+    size_t bitpos = 0;
+    uint8_t tail[16] = {0};
+    size_t tail_from;                         // byte offset from which `tail` takes over
 
-    void refill()
+    BitCursor(const uint8_t *bytes, size_t n) : p(bytes), nbytes(n)
     {
-        while (have <= 56 && next < nbytes) {
-            window |= (uint64_t)p[next++] << (56 - have);
-            have += 8;
-        }
+        tail_from = n >= 8 ? n - 8 : 0;
+        for (size_t i = tail_from; i < n; ++i) tail[i - tail_from] = bytes[i];
     }
-    bool take(int n, unsigned *out)      // 1 <= n <= 16
+    uint64_t peek() const
     {
-        if (have < n) {
-            refill();
-            if (have < n) return false;
-        }
-        *out = (unsigned)(window >> (64 - n));
-        window <<= n;
-        have -= n;
-        return true;
+        const size_t byte = bitpos >> 3;
+        const uint8_t *src = byte < tail_from ? p + byte : tail + (byte - tail_from < 8 ? byte - tail_from : 8);
+        uint64_t w;
+        __builtin_memcpy(&w, src, 8);
+        return __builtin_bswap64(w) << (bitpos & 7);
     }
-    void align_to_byte()                 // drop the zero padding after an EOB
-    {
-        const int drop = have & 7;       // bits consumed so far are a multiple of 8 iff `have` is
-        window <<= drop;
-        have -= drop;
-    }
+    size_t bits_left() const { return nbytes * 8 > bitpos ? nbytes * 8 - bitpos : 0; }
+    void align_to_byte() { bitpos = (bitpos + 7) & ~(size_t)7; }   // drop the zero padding after an EOB
 };
 
 int fail(const char *msg)
@@ -59,31 +54,33 @@ extern "C" int jpegx_host_entropy_decode(const uint8_t *h_bytes, size_t nbytes, 
 {
     if (!h_bytes || !h_zz) return fail("null host pointer");
     if (nblocks <= 0) return fail("block count must be positive");
-    BitReader br{h_bytes, nbytes};
+    BitCursor cur(h_bytes, nbytes);
     for (long long b = 0; b < nblocks; ++b) {
         int16_t *blk = h_zz + b * 64;
-        int n = 0;                                   // coefficients written so far
+        memset(blk, 0, 128);                         // zeros are the common case: only non-zeros are written below
+        int n = 0;                                   // coefficients placed so far
         for (;;) {
-            unsigned run, size;
-            if (!br.take(4, &run) || !br.take(4, &size)) return fail("entropy stream ends inside a block");
-            if (run == 0 && size == 0) {             // EOB: zero fill, skip the byte padding
-                for (; n < 64; ++n) blk[n] = 0;
-                br.align_to_byte();
-                break;
-            }
-            if (run == 15 && size == 0) {            // zero chain: FIFTEEN zeros (util.py:134-154)
-                if (n + 15 > 64) return fail("zero chain overruns the block");
-                for (int i = 0; i < 15; ++i) blk[n++] = 0;
+            if (cur.bits_left() < 8) return fail("entropy stream ends inside a block");
+            const uint64_t w = cur.peek();
+            const unsigned run = (unsigned)(w >> 60), size = (unsigned)(w >> 56) & 15u;
+            if (size == 0) {
+                cur.bitpos += 8;
+                if (run == 0) {                      // EOB: the rest of the block stays zero, skip the byte padding
+                    cur.align_to_byte();
+                    break;
+                }
+                if (run != 15) return fail("BadRleCodeError: zero size with a non-terminal run");
+                if (n + 15 > 64) return fail("zero chain overruns the block");      // FIFTEEN zeros (util.py:134-154)
+                n += 15;
                 continue;
             }
-            if (size == 0) return fail("BadRleCodeError: zero size with a non-terminal run");
-            unsigned bits;
-            if (!br.take((int)size, &bits)) return fail("entropy stream ends inside an amplitude");
+            if (cur.bits_left() < 8 + size) return fail("entropy stream ends inside an amplitude");
+            const unsigned bits = (unsigned)((w << 8) >> (64 - size));
+            cur.bitpos += 8 + size;
             const unsigned mag = bits & ((1u << (size - 1)) - 1u);
-            const int amp = (bits >> (size - 1)) ? (int)mag : -(int)mag;     // sign bit '1' = positive
-            if (n + (int)run + 1 > 64) return fail("run overruns the block");
-            for (unsigned i = 0; i < run; ++i) blk[n++] = 0;
-            blk[n++] = (int16_t)amp;
+            n += (int)run;
+            if (n >= 64) return fail("run overruns the block");
+            blk[n++] = (int16_t)((bits >> (size - 1)) ? (int)mag : -(int)mag);       // sign bit '1' = positive
         }
     }
     return JPEGX_OK;

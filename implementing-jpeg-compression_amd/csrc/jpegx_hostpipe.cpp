@@ -64,7 +64,7 @@ constexpr int MAX_DEVICES = 16;
 struct DevicePool {
     std::mutex mu;                // one host job at a time per device
     hipStream_t stream = nullptr;
-    Span d_in, d_zz, d_ws, d_out;
+    Span d_in, d_zz, d_ws, d_out, d_tmp;
     Span h_in{nullptr, 0, true};
     // state between jpegx_host_compress_begin and _finish (the pool stays locked in between)
     bool open = false;
@@ -123,12 +123,13 @@ int jpegx_host_compress_begin(const void *h_plane, int elem_size, int H, int W, 
                               double param, size_t *nbytes)
 {
     if (!h_plane || !nbytes) return fail(JPEGX_E_INVALID, "null pointer");
-    if (bs != 1 && bs != 2 && bs != 4) return fail(JPEGX_E_UNSUPPORTED, "host_compress supports block_size 1, 2 and 4");
+    if (bs < 1 || bs > 255) return fail(JPEGX_E_UNSUPPORTED, "host_compress supports block_size 1..255");
+    const bool fused_pool = bs == 1 || bs == 2 || bs == 4;   // uint8 kernels with the mean folded in; else pool to float64 first
     if (H <= 0 || W <= 0 || (H % 8) || (W % 8)) return fail(JPEGX_E_INVALID, "plane height and width (after pooling) must be positive multiples of 8");
     if (elem_size != 1 && elem_size != 4 && elem_size != 8) return fail(JPEGX_E_UNSUPPORTED, "host_compress takes uint8, int32 or int64 samples");
     const int HH = H * bs, WW = W * bs;
     if (pitch < WW) return fail(JPEGX_E_INVALID, "pitch smaller than the row");
-    if ((WW % 16) != 0) return fail(JPEGX_E_UNSUPPORTED, "host_compress needs rows of a multiple of 16 samples");
+    if (fused_pool && (WW % 16) != 0) return fail(JPEGX_E_UNSUPPORTED, "host_compress needs rows of a multiple of 16 samples");
     DevicePool *pool = nullptr;
     int rc = current_pool(&pool);
     if (rc) return rc;
@@ -157,9 +158,19 @@ int jpegx_host_compress_begin(const void *h_plane, int elem_size, int H, int W, 
         ? hipMemcpyAsync(pool->d_in.p, src8, in_bytes, hipMemcpyHostToDevice, st)
         : hipMemcpy2DAsync(pool->d_in.p, WW, src8, (size_t)src_pitch, WW, HH, hipMemcpyHostToDevice, st);
     if (e != hipSuccess) return bail(fail(JPEGX_E_HIP, "host to device copy failed"));
-    if ((rc = jpegx_forward_fused_u8(static_cast<const uint8_t *>(pool->d_in.p), H, W, WW, bs, mode, param, 0,
-                                     static_cast<int16_t *>(pool->d_zz.p), st)) ||
-        (rc = jpegx_entropy_sizes(static_cast<const int16_t *>(pool->d_zz.p), nblocks, pool->d_ws.p, st)))
+    if (fused_pool) {
+        rc = jpegx_forward_fused_u8(static_cast<const uint8_t *>(pool->d_in.p), H, W, WW, bs, mode, param, 0,
+                                    static_cast<int16_t *>(pool->d_zz.p), st);
+    } else {
+        // any other block_size: SubSampling on the device in float64 (exact sum, one division), then the
+        // all-float64 fused forward -- k/9, k/25 ... are not fp32 numbers
+        if ((rc = pool->d_tmp.ensure((size_t)H * W * 8))) return bail(rc);
+        rc = jpegx_mean_pool_f64(pool->d_in.p, 1, H, W, WW, bs, static_cast<double *>(pool->d_tmp.p), W, st);
+        if (!rc)
+            rc = jpegx_forward_fused_f64(static_cast<const double *>(pool->d_tmp.p), H, W, W, mode, param, 0,
+                                         static_cast<int16_t *>(pool->d_zz.p), st);
+    }
+    if (rc || (rc = jpegx_entropy_sizes(static_cast<const int16_t *>(pool->d_zz.p), nblocks, pool->d_ws.p, st)))
         return bail(rc);
     unsigned long long total = 0;
     if ((rc = jpegx_entropy_total(pool->d_ws.p, &total, st))) return bail(rc);      // synchronises
@@ -240,7 +251,7 @@ int jpegx_host_pool_release(void)
     int rc = current_pool(&pool);
     if (rc) return rc;
     std::lock_guard<std::mutex> lock(pool->mu);
-    for (Span *s : {&pool->d_in, &pool->d_zz, &pool->d_ws, &pool->d_out, &pool->h_in}) {
+    for (Span *s : {&pool->d_in, &pool->d_zz, &pool->d_ws, &pool->d_out, &pool->d_tmp, &pool->h_in}) {
         if (s->p) { if (s->pinned) (void)hipHostFree(s->p); else (void)hipFree(s->p); }
         s->p = nullptr;
         s->cap = 0;

@@ -386,6 +386,15 @@ int jpegx_inverse_fused_u8_inflated(const int16_t *d_in, int H, int W, int mode,
     if (bs != 1 && bs != 2 && bs != 4) return fail(JPEGX_E_UNSUPPORTED, "fused inflate supports block_size 1, 2 and 4");
     return inverse_common(d_in, H, W, mode, param, flags, d_out, out_pitch, JPEGX_OUT_U8, bs, stream);
 }
+int jpegx_host_inverse_fused_u8_inflated(const int16_t *h_in, int H, int W, int mode, double param, unsigned flags, int bs,
+                                         uint8_t *h_out, ptrdiff_t out_pitch)
+{
+    if (H <= 0 || W <= 0 || bs < 1 || out_pitch < (ptrdiff_t)W * bs) return fail(JPEGX_E_INVALID, "bad plane shape");
+    return host_roundtrip(h_in, (size_t)H * W * 2, h_out, (size_t)H * bs * out_pitch, [&](void *di, void *dout, jpegx_stream_t s) {
+        return jpegx_inverse_fused_u8_inflated((const int16_t *)di, H, W, mode, param, flags, bs, (uint8_t *)dout, out_pitch, s);
+    });
+}
+
 int jpegx_host_inverse_fused(const int16_t *h_in, int H, int W, int mode, double param, unsigned flags, void *h_out,
                              ptrdiff_t out_pitch, int out_type)
 {

@@ -85,6 +85,22 @@ __global__ void k_zigzag(const T *__restrict__ in, size_t pitch, int wb, size_t 
     if (INVERSE) out[nat] = in[t]; else out[t] = in[nat];
 }
 
+// SubSampling.execute (pipeline/subsampling.py:9-11) for ANY block_size: np.mean over bs x bs tiles of an
+// integer-valued band = the exact sum (integers, far below 2^53) divided once in float64.  One thread per
+// output sample; a wave reads 64 * bs contiguous samples of each input row.
+template <typename T>
+__global__ void k_mean_pool_f64(const T *__restrict__ in, size_t pitch, int H, int W, int bs, double *__restrict__ out,
+                                size_t opitch)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= W || y >= H) return;
+    const T *p = in + (size_t)y * bs * pitch + (size_t)x * bs;
+    double s = 0.0;
+    for (int u = 0; u < bs; ++u)
+        for (int w = 0; w < bs; ++w) s += (double)p[(size_t)u * pitch + w];
+    out[(size_t)y * opitch + x] = s / (double)(bs * bs);
+}
+
 __global__ void k_generate_plane(float *__restrict__ out, size_t pitch, int H, int W, int kind, uint32_t pseed,
                                  uint32_t row0)
 {
@@ -138,6 +154,25 @@ int jpegx_generate_plane(float *d_plane, int H, int W, ptrdiff_t pitch, int kind
     HIP_TRY(hipGetLastError());
     return JPEGX_OK;
 }
+int jpegx_mean_pool_f64(const void *d_in, int elem_size, int H, int W, ptrdiff_t pitch, int bs, double *d_out,
+                        ptrdiff_t out_pitch, jpegx_stream_t stream)
+{
+    if (!d_in || !d_out) return fail(JPEGX_E_INVALID, "null device pointer");
+    if (H <= 0 || W <= 0 || bs < 1 || bs > 4096) return fail(JPEGX_E_INVALID, "mean_pool: bad shape or block_size");
+    if (pitch < (ptrdiff_t)W * bs || out_pitch < W) return fail(JPEGX_E_INVALID, "pitch smaller than the row");
+    if (H > 65535) return fail(JPEGX_E_UNSUPPORTED, "mean_pool: more than 65535 output rows in one launch");
+    const dim3 block(256), grid((W + 255) / 256, H);
+    hipStream_t st = (hipStream_t)stream;
+    if (elem_size == 1)
+        hipLaunchKernelGGL((k_mean_pool_f64<uint8_t>), grid, block, 0, st, (const uint8_t *)d_in, (size_t)pitch, H, W, bs, d_out, (size_t)out_pitch);
+    else if (elem_size == 4)
+        hipLaunchKernelGGL((k_mean_pool_f64<float>), grid, block, 0, st, (const float *)d_in, (size_t)pitch, H, W, bs, d_out, (size_t)out_pitch);
+    else
+        return fail(JPEGX_E_UNSUPPORTED, "mean_pool takes uint8 (elem_size 1) or integer-valued fp32 (elem_size 4) samples");
+    HIP_TRY(hipGetLastError());
+    return JPEGX_OK;
+}
+
 int jpegx_dct8x8_f32(const float *d_in, int H, int W, ptrdiff_t pitch, float *d_out, ptrdiff_t out_pitch,
                      jpegx_stream_t stream)
 {

@@ -72,6 +72,8 @@ SIGNATURES = {
     "jpegx_forward_fused_pooled": [_vp, _int, _int, _pd, _int, _int, _dbl, _uint, _vp, _vp],
     "jpegx_forward_fused_u8": [_vp, _int, _int, _pd, _int, _int, _dbl, _uint, _vp, _vp],
     "jpegx_forward_fused_planes": [_vp, _int, _int, _dbl, _uint, _vp],
+    "jpegx_forward_fused_f64": [_vp, _int, _int, _pd, _int, _dbl, _uint, _vp, _vp],
+    "jpegx_mean_pool_f64": [_vp, _int, _int, _int, _pd, _int, _vp, _pd, _vp],
     "jpegx_inverse_fused": [_vp, _int, _int, _int, _dbl, _uint, _vp, _pd, _int, _vp],
     "jpegx_inverse_fused_u8_inflated": [_vp, _int, _int, _int, _dbl, _uint, _int, _vp, _pd, _vp],
     "jpegx_dct8x8_f32": [_vp, _int, _int, _pd, _vp, _pd, _vp],
@@ -83,7 +85,9 @@ SIGNATURES = {
     "jpegx_zigzag": [_vp, _int, _int, _pd, _int, _vp, _vp],
     "jpegx_unzigzag": [_vp, _int, _int, _int, _vp, _pd, _vp],
     "jpegx_host_forward_fused": [_vp, _int, _int, _pd, _int, _dbl, _uint, _vp],
+    "jpegx_host_forward_fused_f64": [_vp, _int, _int, _int, _dbl, _uint, _vp],
     "jpegx_host_inverse_fused": [_vp, _int, _int, _int, _dbl, _uint, _vp, _pd, _int],
+    "jpegx_host_inverse_fused_u8_inflated": [_vp, _int, _int, _int, _dbl, _uint, _int, _vp, _pd],
     "jpegx_host_dct8x8_f64": [_vp, _int, _int, _vp],
     "jpegx_host_idct8x8_f64": [_vp, _int, _int, _vp, _int],
     "jpegx_host_quantize_f64": [_vp, _int, _int, _int, _dbl, _vp],
@@ -314,6 +318,37 @@ def forward_fused(plane, mode="qtable", param=0.0, pixel_input=None, flags_extra
     return out
 
 
+def mean_pool_f64(plane, block_size):
+    """SubSampling.execute on the device for any block_size: uint8 / integer-valued fp32 plane -> float64 means."""
+    a = np.ascontiguousarray(plane)
+    if a.dtype != np.uint8:
+        a = a.astype(np.float32)
+    bs = int(block_size)
+    hh, ww = a.shape
+    if hh % bs or ww % bs:
+        raise JpegxError("plane must be a multiple of block_size in both dimensions")
+    h, w = hh // bs, ww // bs
+    din, dout = DeviceBuffer(a.nbytes), DeviceBuffer(h * w * 8)
+    try:
+        din.upload(a)
+        check(lib().jpegx_mean_pool_f64(din.ptr, a.dtype.itemsize, h, w, ww, bs, dout.ptr, w, None), "jpegx_mean_pool_f64")
+        return dout.download((h, w), np.float64)
+    finally:
+        din.free()
+        dout.free()
+
+
+def forward_fused_f64(plane, mode="qtable", param=0.0):
+    """float64 plane (H, W) -> int16 (H/8, W/8, 64): steps 4+5+6 entirely in float64 in the reference's
+    operation order (for samples that are not exact in fp32)."""
+    a = _plane(plane, np.float64)
+    h, w = a.shape
+    out = np.empty((h // 8, w // 8, 64), dtype=np.int16)
+    check(lib().jpegx_host_forward_fused_f64(a.ctypes.data, h, w, mode_of(mode), float(param), 0, out.ctypes.data),
+          "jpegx_host_forward_fused_f64")
+    return out
+
+
 def forward_fused_pooled(plane, block_size, mode="qtable", param=0.0, pixel_input=None):
     """Like forward_fused with the SubSampling mean-pool (block_size in 1,2,4) fused in."""
     a = _plane(plane, np.float32)
@@ -376,16 +411,11 @@ def inverse_fused_u8(zz, mode="qtable", param=0.0, inflate=1):
         raise JpegxError("expected a (H/8, W/8, 64) coefficient stream, got %r" % (z.shape,))
     h, w = z.shape[0] * 8, z.shape[1] * 8
     bs = int(inflate)
-    out = np.empty((h * bs, w * bs), dtype=np.uint8)
-    din, dout = DeviceBuffer(z.nbytes), DeviceBuffer(out.nbytes)
-    try:
-        din.upload(z)
-        check(lib().jpegx_inverse_fused_u8_inflated(din.ptr, h, w, mode_of(mode), float(param), 0, bs, dout.ptr,
-                                                    w * bs, None), "jpegx_inverse_fused_u8_inflated")
-        return dout.download(out.shape, np.uint8)
-    finally:
-        din.free()
-        dout.free()
+    pitch = (w * bs + 15) // 16 * 16                         # the kernel wants 16-byte aligned rows
+    out = np.empty((h * bs, pitch), dtype=np.uint8)
+    check(lib().jpegx_host_inverse_fused_u8_inflated(z.ctypes.data, h, w, mode_of(mode), float(param), 0, bs,
+                                                     out.ctypes.data, pitch), "jpegx_host_inverse_fused_u8_inflated")
+    return out[:, :w * bs]
 
 
 def dct8x8_f64(a):
@@ -509,7 +539,9 @@ def compress_plane_native(plane, block_size=1, mode="qtable", param=0.0):
     if elem is None or src.ndim != 2 or not src.flags.c_contiguous:
         return None
     hh, ww = src.shape
-    if hh == 0 or hh % (8 * bs) or ww % (8 * bs) or ww % 16 or not u8_path_ok(ww // bs, bs, ww, mode, param):
+    if hh == 0 or hh % (8 * bs) or ww % (8 * bs) or not 1 <= bs <= 255:
+        return None
+    if bs in (1, 2, 4) and (ww % 16 or not u8_path_ok(ww // bs, bs, ww, mode, param)):
         return None
     L = lib()
     n = ctypes.c_size_t(0)

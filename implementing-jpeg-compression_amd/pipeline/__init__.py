@@ -109,7 +109,12 @@ def _hot_forward(pre, config):
     as32 = pre.astype(np.float32)
     if np.array_equal(as32.astype(np.float64), pre.astype(np.float64)):
         return jpegx.forward_fused(as32, mode, param).astype(np.float64)
-    coeffs = jpegx.quantize_f64(jpegx.dct8x8_f64(pre.astype(np.float64)), mode, param)
+    pre = pre.astype(np.float64)
+    if pre.shape[1] % 2 == 0:
+        zz = jpegx.forward_fused_f64(pre, mode, param)          # one all-float64 launch
+        if np.abs(zz).max() < 32767:                            # int16 saturation would hide larger values
+            return zz.astype(np.float64)
+    coeffs = jpegx.quantize_f64(jpegx.dct8x8_f64(pre), mode, param)
     return jpegx.zigzag(coeffs)
 
 
@@ -163,7 +168,7 @@ def _front_end_fused(band, config, with_entropy):
     device.  Returns None when not applicable."""
     bs = config.block_size
     band = np.asarray(band)
-    if bs not in (1, 2, 4) or band.ndim != 2 or band.size == 0 or band.dtype.kind not in "ui":
+    if not 1 <= bs <= 255 or band.ndim != 2 or band.size == 0 or band.dtype.kind not in "ui":
         return None
     import jpegx
     mode, param = config.quantization.gpu_mode()
@@ -173,7 +178,7 @@ def _front_end_fused(band, config, with_entropy):
         blob = jpegx.compress_plane_native(np.ascontiguousarray(padded), bs, mode, param)
         if blob is not None:
             return blob
-    if band.dtype != np.uint8 and (band.min() < 0 or band.max() > 255):
+    if bs not in (1, 2, 4) or (band.dtype != np.uint8 and (band.min() < 0 or band.max() > 255)):
         return None
     if padded.shape[0] % (8 * bs) or padded.shape[1] % (8 * bs):
         # DCT padding is needed: it replicates POOLED edge samples (dct_padding.py:8-9), so pool on
@@ -201,11 +206,14 @@ def _back_end_fused(zz, config):
     mode, param = config.quantization.gpu_mode()
     if bs not in (1, 2, 4) or zz.ndim != 3 or zz.shape[2] != 64 or zz.size == 0:
         return None
-    if np.abs(zz).max() > 32767 or not np.array_equal(zz, np.rint(zz)) or \
-            (mode == "divide" and abs(param) * 32767 >= 2 ** 24):
+    if mode == "divide" and abs(param) * 32767 >= 2 ** 24:
         return None
+    if zz.dtype != np.int16:                  # the C++ entropy decoder hands over int16; anything else is checked
+        if np.abs(zz).max() > 32767 or not np.array_equal(zz, np.rint(zz)):
+            return None
+        zz = zz.astype(np.int16)
     import jpegx
-    full = jpegx.inverse_fused_u8(zz.astype(np.int16), mode, param, inflate=bs)
+    full = jpegx.inverse_fused_u8(zz, mode, param, inflate=bs)
     return full[:config.height, :config.width].astype(int)
 
 

@@ -127,6 +127,18 @@ int jpegx_forward_fused(const float *d_in, int H, int W, ptrdiff_t pitch, int mo
 int jpegx_forward_fused_pooled(const float *d_in, int H, int W, ptrdiff_t pitch, int bs, int mode,
                                double param, unsigned flags, int16_t *d_out, jpegx_stream_t stream);
 
+/* The same on a FLOAT64 plane, everything in float64 in the reference's operation order (bit-exact by
+ * construction): the input of step 4 when samples are not exact in fp32, e.g. after SubSampling with
+ * block_size 3, 5, 6 ... (pipeline/subsampling.py:9-11).  pitch in elements, even.               */
+int jpegx_forward_fused_f64(const double *d_in, int H, int W, ptrdiff_t pitch, int mode, double param,
+                            unsigned flags, int16_t *d_out, jpegx_stream_t stream);
+
+/* SubSampling.execute for ANY block_size (pipeline/subsampling.py:9-11, np.mean of bs x bs tiles): d_in is
+ * [H*bs][pitch] of uint8 (elem_size 1) or integer-valued fp32 (elem_size 4); d_out [H][out_pitch] float64:
+ * the exact tile sum divided once, which is what np.mean returns for integer bands.             */
+int jpegx_mean_pool_f64(const void *d_in, int elem_size, int H, int W, ptrdiff_t pitch, int bs,
+                        double *d_out, ptrdiff_t out_pitch, jpegx_stream_t stream);
+
 /* Several planes in ONE launch (BASELINE.json configs[2]: the Y, Cb and Cr bands that
  * pipeline/__init__.py:104-106 compresses one after another): every descriptor is one
  * jpegx_forward_fused_pooled job; the pooled planes' workgroups are dispatched first and the
@@ -238,8 +250,12 @@ int jpegx_comm_gather_bytes(jpegx_comm_t comm, const void *d_send, size_t send_b
 /* ---- synchronous host-pointer conveniences (H2D, kernel, D2H on an internal stream) ------ */
 int jpegx_host_forward_fused(const float *h_in, int H, int W, ptrdiff_t pitch, int mode,
                              double param, unsigned flags, int16_t *h_out);
+int jpegx_host_forward_fused_f64(const double *h_in, int H, int W, int mode, double param, unsigned flags,
+                                 int16_t *h_out);
 int jpegx_host_inverse_fused(const int16_t *h_in, int H, int W, int mode, double param,
                              unsigned flags, void *h_out, ptrdiff_t out_pitch, int out_type);
+int jpegx_host_inverse_fused_u8_inflated(const int16_t *h_in, int H, int W, int mode, double param,
+                                         unsigned flags, int bs, uint8_t *h_out, ptrdiff_t out_pitch);
 int jpegx_host_dct8x8_f64(const double *h_in, int H, int W, double *h_out);
 int jpegx_host_idct8x8_f64(const double *h_in, int H, int W, double *h_out, int do_round);
 int jpegx_host_quantize_f64(const double *h_in, int H, int W, int mode, double param, double *h_out);
@@ -255,7 +271,8 @@ int jpegx_host_idct8x8_f32(const float *h_in, int H, int W, float *h_out);
  * JPEGX_E_UNSUPPORTED) and narrowed by a few host threads.  _begin uploads, runs steps 1+4+5+6 (fused) and
  * 7+8 (device entropy stage) on the device's pooled stream and buffers, and reports the size of the byte
  * stream; _finish copies it into h_out (>= that many bytes).  Between the two calls the device's pool is
- * held by the calling thread; _abort gives it back without copying.  W*bs must be a multiple of 16.      */
+ * held by the calling thread; _abort gives it back without copying.  bs 1, 2, 4: the uint8 kernels with
+ * the mean folded in (W*bs a multiple of 16); any other bs: jpegx_mean_pool_f64 + jpegx_forward_fused_f64. */
 int jpegx_host_compress_begin(const void *h_plane, int elem_size, int H, int W, ptrdiff_t pitch, int bs,
                               int mode, double param, size_t *nbytes);
 int jpegx_host_compress_finish(uint8_t *h_out);

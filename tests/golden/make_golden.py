@@ -257,6 +257,8 @@ def main():
     run_case("ties128", ties)
     # 2x2 mean-pooled chroma-like plane (block_size=2): 128x128 -> 64x64, values k/4
     run_case("pooled128", synth.generate_plane("noise", 128, 128, seed=7, dtype=np.int64), block_size=2)
+    # 3x3 mean-pooled plane (block_size=3): 72x96 -> 24x32, values k/9 (NOT fp32 numbers: float64 path)
+    run_case("pooled3x72", synth.generate_plane("noise", 72, 96, seed=5, dtype=np.int64), block_size=3)
     # ragged size: 20 rows x 28 cols -> DCT padding to 24 x 32 (edge replication)
     run_case("ragged20x28", synth.generate_plane("smooth", 20, 28, seed=3, dtype=np.int64))
     # extremes: all-zero, all-255, 0/255 checkerboard and stripes (max |AC|)

@@ -224,3 +224,26 @@ def test_amplitudes_beyond_15_bits_raise_the_reference_exception(gpu):
         gpu.forward_fused_u8(band.astype(np.uint8), 1, "divide", 0.01)
     with pytest.raises(util.BadRleCodeError):
         decompress_band(b"\x30\x00", cfg)                    # run 3 with size 0: not a legal code
+
+
+def test_block_size_3_runs_on_the_device_and_matches_the_reference(gpu, golden):
+    """block_size 3 (means k/9 are not fp32 numbers): SubSampling on the device in float64 (jpegx_mean_pool_f64),
+    the all-float64 fused forward (jpegx_forward_fused_f64) and the device entropy stage -- no host pooling --
+    against the reference's arrays for the same band (case_pooled3x72.npz)."""
+    c = golden("pooled3x72")
+    band = c["input"].astype(np.int64)
+    assert np.array_equal(gpu.mean_pool_f64(band.astype(np.uint8), 3), c["pre"])
+    assert np.array_equal(gpu.mean_pool_f64(band.astype(np.float32), 3), c["pre"])
+    for suffix, mk in METHODS:
+        assert np.array_equal(gpu.forward_fused_f64(c["pre"], *mk().gpu_mode()), c["zz_" + suffix])
+        cfg = config_for(c, mk())
+        for b in (band, band.astype(np.uint8)):
+            blob = compress_band(b, cfg)
+            assert isinstance(blob, bytes)
+            zz = RunLengthEncoding(cfg).invert(RleBytestream(cfg).invert(blob))
+            assert np.array_equal(zz, c["zz_" + suffix])
+            assert np.array_equal(decompress_band(blob, cfg), c["band_" + suffix])
+    # the native path really took it (not the host-pooling fallback)
+    assert gpu.compress_plane_native(band, 3, "qtable", 0.0) == compress_band(band, config_for(c, QuantizationMethod("qtable")))
+    # a float64 plane straight into steps 4-6 (BasisChange input that is not exact in fp32)
+    assert np.array_equal(pipeline._hot_forward(c["pre"], config_for(c, QuantizationMethod("qtable"))), c["zz_qtable"].astype(np.float64))

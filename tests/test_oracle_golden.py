@@ -211,3 +211,15 @@ def test_container_bytes_match_the_reference():
             (d["width"], d["height"], d["block_size"], d["dct_size"], d["transform"])
         assert back.quantization.name == (d["q"][0] if d["q"] else "none")
         assert [data.y, data.cb, data.cr] == parts
+
+
+def test_block_size_3_case_from_the_reference(golden):
+    """SubSampling with block_size 3 gives k/9 -- not fp32 numbers; the oracle's float64 chain reproduces the
+    reference's arrays for it (tests/golden/case_pooled3x72.npz)."""
+    c = golden("pooled3x72")
+    pre = oracle.mean_pool(c["input"].astype(np.float64), 3)
+    assert np.array_equal(pre, c["pre"]) and not np.array_equal(pre.astype(np.float32).astype(np.float64), pre)
+    dct = oracle.dct_plane(pre)
+    assert np.array_equal(dct, c["dct"])
+    for suffix, mode, param in MODES:
+        assert np.array_equal(oracle.zigzag_plane(oracle.quant_plane(dct, mode, param)), c["zz_" + suffix].astype(np.float64))
