@@ -63,6 +63,7 @@ def parse_args():
     ap.add_argument("--spinup-ms", type=float, default=60.0,
                     help="untimed launches before the W warm-up steps so that the GPU leaves its idle clocks")
     ap.add_argument("--gather-chunk", type=int, default=4, help="planes per send/recv round of the overlapped gather")
+    ap.add_argument("--gather-timeout", type=float, default=240.0, help="seconds the gather legs may take before rank 0 reports without them")
     ap.add_argument("--share-device", action="store_true",
                     help="rehearsal on ONE GPU: every rank uses GPU 0 and a 1-rank RCCL communicator "
                          "(loop-back send/recv); exercises launcher, control plane, events and streams")
@@ -353,12 +354,6 @@ def run(args, rank, local_rank, world, ctl):
             verified = verified and bool(np.array_equal(got, want))
         verified = bool(all(ctl.allgather(verified)))
 
-    # --- the one exchange of the path: RCCL gather of the int16 stream to rank 0 -------------------
-    gather = end_to_end = None
-    if gathering:
-        gather, end_to_end = gather_legs(args, jpegx, multigpu, ctl, rank, world, spans, in_ptr, out_ptr, root_ptr,
-                                         plane_out, total_blocks_per_step, loopback)
-
     achieved = BYTES_PER_BLOCK * blocks_per_step / (kernel_ms * 1e-3) / 1e9
     # HBM traffic per launch from the committed rocprofv3 PMC passes of this same command, accepted only
     # while the kernel sources are the ones that were profiled (profiles/summarize.py records their hash)
@@ -393,10 +388,31 @@ def run(args, rank, local_rank, world, ctl):
         "verified_vs_oracle": verified,
         "device": jpegx.device_name(device),
     }
-    if gather is not None:
-        result["gather"] = gather
-    if end_to_end is not None:
-        result["end_to_end"] = end_to_end
+    # --- the one exchange of the path: RCCL gather of the int16 stream to rank 0 -------------------
+    # The compute-phase result above is complete at this point.  A watchdog guards it: should the gather
+    # (the only part that waits on other GPUs) not come back within --gather-timeout seconds, rank 0 still
+    # prints the line, with the timeout recorded under "gather", and every rank leaves.
+    if gathering:
+        import threading
+
+        def give_up():
+            result["gather"] = {"error": "gather legs did not finish within %.0f s; compute-phase result kept" % args.gather_timeout}
+            if rank == 0:
+                print(json.dumps(result), flush=True)
+            os._exit(0 if rank == 0 else 3)
+        dog = threading.Timer(args.gather_timeout, give_up)
+        dog.daemon = True
+        dog.start()
+        try:
+            gather, end_to_end = gather_legs(args, jpegx, multigpu, ctl, rank, world, spans, in_ptr, out_ptr, root_ptr,
+                                             plane_out, total_blocks_per_step, loopback)
+        except multigpu.ControlPlaneError as exc:      # a rank dropped out: keep the measured compute phase
+            gather, end_to_end = {"error": "control plane: %s" % str(exc)[:300]}, None
+        dog.cancel()
+        if gather is not None:
+            result["gather"] = gather
+        if end_to_end is not None:
+            result["end_to_end"] = end_to_end
     if rank == 0 and world == 1:
         if not args.no_configs:
             # free the batch first: the legs below allocate their own planes
@@ -415,7 +431,10 @@ def run(args, rank, local_rank, world, ctl):
             result["cpu_baseline"] = cpu_baseline(size, args.kind)
     if rank == 0:
         print(json.dumps(result), flush=True)
-    ctl.barrier()
+    try:
+        ctl.barrier()
+    except multigpu.ControlPlaneError:
+        pass                                            # the line is out; a peer that already left is not an error here
 
 
 def gather_legs(args, jpegx, multigpu, ctl, rank, world, spans, in_ptr, out_ptr, root_ptr, plane_out,

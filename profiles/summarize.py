@@ -11,6 +11,7 @@ exactly half of the bytes of a wide (16 B per lane) coalesced read stream, so it
 """
 import csv
 import glob
+import hashlib
 import json
 import os
 import shutil
@@ -47,13 +48,33 @@ def main():
                                    "min_ns": min(d), "vgpr": first["VGPR_Count"], "sgpr": first["SGPR_Count"],
                                    "lds_bytes": first["LDS_Block_Size"], "workgroup": first["Workgroup_Size_X"],
                                    "grid": first["Grid_Size_X"]}
+    # which kernel sources the numbers belong to: bench.py accepts the traffic figure only while this matches
+    repo = os.path.dirname(here)
+    sys.path.insert(0, repo)
+    try:
+        from bench import FORWARD_SOURCES
+        h = hashlib.sha256()
+        for rel in FORWARD_SOURCES:
+            with open(os.path.join(repo, rel), "rb") as fsrc:
+                h.update(fsrc.read())
+        summary["forward_source_sha16"] = h.hexdigest()[:16]
+    except Exception as exc:   # pragma: no cover
+        summary["forward_source_sha16"] = None
+        summary["forward_source_sha16_error"] = str(exc)
     f = counters(prefix + "_fetch", kernel).get("FETCH_SIZE")
     w = counters(prefix + "_write", kernel).get("WRITE_SIZE")
     if f and w:
         rd = 2.0 * f["median"] * 1024.0          # gfx950: FETCH_SIZE counts 64 B per 128 B request
         wr = w["median"] * 1024.0
+        blocks = None
+        pmc_files = glob.glob(os.path.join(prefix + "_fetch", "*", "*_counter_collection.csv"))
+        for row in csv.DictReader(open(pmc_files[0])):
+            if kernel in row["Kernel_Name"]:
+                blocks = int(row["Grid_Size"])              # 64 threads = 64 blocks per workgroup
+                break
         summary["hbm_traffic"] = {"FETCH_SIZE_KiB_median": f["median"], "WRITE_SIZE_KiB_median": w["median"],
                                   "read_bytes_corrected": rd, "write_bytes": wr, "total_bytes_per_launch": rd + wr,
+                                  "blocks_per_launch": blocks, "bytes_per_block": (rd + wr) / blocks if blocks else None,
                                   "correction": "read = 2 x FETCH_SIZE x 1024 (MI355X_MICROARCH.md, HBM); write = WRITE_SIZE x 1024"}
     sq = counters(prefix + "_sq", kernel)
     if sq:
