@@ -240,14 +240,22 @@ def main():
     rank, local_rank, world = multigpu.rank_env()
     if args.gpus != world:
         raise SystemExit("bench.py --gpus %d was started inside a job of %d ranks" % (args.gpus, world))
+    # stdout belongs to the ONE result line: libraries underneath (RCCL prints a version banner on
+    # communicator creation) get stderr instead; emit() writes to the real stdout
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj):
+        os.write(real_stdout, (json.dumps(obj) + "\n").encode())
     ctl = multigpu.ControlPlane(rank, world)
     try:
-        run(args, rank, local_rank, world, ctl)
+        run(args, rank, local_rank, world, ctl, emit)
     finally:
         ctl.close()
 
 
-def run(args, rank, local_rank, world, ctl):
+def run(args, rank, local_rank, world, ctl, emit):
     from jpegx import multigpu
     size, total_planes = args.size, args.planes_total
     spans = [multigpu.shard_planes(total_planes, world, r) for r in range(world)]
@@ -267,8 +275,8 @@ def run(args, rank, local_rank, world, ctl):
         t = ctl.allreduce_max(float(rank))
         ctl.barrier()
         if rank == 0:
-            print(json.dumps({"dry_run": True, "n_gpus": world, "shards": [s[1:3] for s in seen], "all_ok": ok,
-                              "max_rank": t, "launcher": os.environ.get("JPEGX_LAUNCHER", "external")}), flush=True)
+            emit({"dry_run": True, "n_gpus": world, "shards": [s[1:3] for s in seen], "all_ok": ok,
+                  "max_rank": t, "launcher": os.environ.get("JPEGX_LAUNCHER", "external")})
         return
 
     import jpegx
@@ -297,6 +305,9 @@ def run(args, rank, local_rank, world, ctl):
     # synthetic planes generated on the device; plane ids are those of the whole batch
     for p in range(planes):
         jpegx.generate_plane_device(in_ptr + p * plane_in, size, size, args.kind, seed=0, plane=lo + p, stream=stream)
+    # first touch of the output span by a fill, not by the first transform launch (mapping 32 GiB of fresh
+    # pages inside that launch made it 6x longer than the others in the rocprofv3 trace)
+    jpegx.check(L.jpegx_memset(out_ptr, 0, planes * plane_out, stream), "memset")
     jpegx.check(L.jpegx_stream_synchronize(stream), "sync")
 
     flags = jpegx.F_PIXEL_INPUT
@@ -398,7 +409,7 @@ def run(args, rank, local_rank, world, ctl):
         def give_up():
             result["gather"] = {"error": "gather legs did not finish within %.0f s; compute-phase result kept" % args.gather_timeout}
             if rank == 0:
-                print(json.dumps(result), flush=True)
+                emit(result)
             os._exit(0 if rank == 0 else 3)
         dog = threading.Timer(args.gather_timeout, give_up)
         dog.daemon = True
@@ -430,7 +441,7 @@ def run(args, rank, local_rank, world, ctl):
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(size, args.kind)
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        emit(result)
     try:
         ctl.barrier()
     except multigpu.ControlPlaneError:

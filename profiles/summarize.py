@@ -43,6 +43,14 @@ def main():
         tr = glob.glob(prefix + "_kt/*/*_kernel_trace.csv")
         d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in csv.DictReader(open(tr[0]))
              if kernel in r["Kernel_Name"]]
+        # the bench launches this kernel at several sizes (the 1024-plane batch, and 16 planes inside the
+        # configs[3] leg): the roofline figure is about the largest one, so group the trace by grid size
+        by_grid = {}
+        for r in csv.DictReader(open(tr[0])):
+            if kernel in r["Kernel_Name"]:
+                by_grid.setdefault(int(r["Grid_Size_X"]), []).append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        summary["kernel_trace_by_grid"] = {str(g): {"dispatches": len(v), "mean_ns": sum(v) / len(v), "median_ns": statistics.median(v),
+                                                    "min_ns": min(v), "max_ns": max(v)} for g, v in sorted(by_grid.items())}
         first = next(r for r in csv.DictReader(open(tr[0])) if kernel in r["Kernel_Name"])
         summary["kernel_trace"] = {"dispatches": len(d), "median_ns": statistics.median(d), "mean_ns": sum(d) / len(d),
                                    "min_ns": min(d), "vgpr": first["VGPR_Count"], "sgpr": first["SGPR_Count"],
