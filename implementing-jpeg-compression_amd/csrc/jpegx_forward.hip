@@ -180,28 +180,35 @@ __device__ __forceinline__ void forward_fused_body(unsigned char *lds, int wg, c
     census(counters, flagged, nblk - g0, lane);
     if (prm.tune & 1) flagged = 0;
     __syncthreads();
-    while (flagged) {
-        const int b = __ffsll((long long)flagged) - 1;
-        flagged &= flagged - 1;
-        const int gb = g0 + b;
-        const int byb = gb / wb, bxb = gb - byb * wb;
+    if (flagged) {
+        // Every vector load in here waits behind the wave's neighbours' streaming traffic, so: the lane's
+        // quantiser entry is fetched once, and the samples of the NEXT flagged block are requested before
+        // the cooperative pass of the current one (one memory round trip per wave instead of one per block).
+        const double rq_lane = c_rq64.v[lane];
         const int i = lane >> 3, j = lane & 7;
-        const float *p = in + ((size_t)(byb * 8 + i) * BS) * pitch + (size_t)(bxb * 8 + j) * BS;
-        double a;
-        if (BS == 1) {
-            a = (double)p[0];
-        } else {
+        auto fetch = [&](int b) -> double {
+            const int gb = g0 + b;
+            const int byb = gb / wb, bxb = gb - byb * wb;
+            const float *p = in + ((size_t)(byb * 8 + i) * BS) * pitch + (size_t)(bxb * 8 + j) * BS;
+            if (BS == 1) return (double)p[0];
             double s = 0.0;  // np.mean: float64 sum then one division (subsampling.py:11)
 #pragma unroll
             for (int u = 0; u < BS; ++u)
 #pragma unroll
                 for (int w = 0; w < BS; ++w) s += (double)p[(size_t)u * pitch + w];
-            a = s / (double)(BS * BS);
+            return s / (double)(BS * BS);
+        };
+        double a_next = fetch(__ffsll((long long)flagged) - 1);
+        while (flagged) {
+            const int b = __ffsll((long long)flagged) - 1;
+            flagged &= flagged - 1;
+            const double a = a_next;
+            if (flagged) a_next = fetch(__ffsll((long long)flagged) - 1);
+            const double y = coop_fwd_exact(a, sA, sM, lane);
+            const double r = jpegx_quant_lane(y, lane, prm.mode, prm.param, rq_lane);
+            const int pz = c_zzinv.v[lane];
+            *reinterpret_cast<int16_t *>(lds + tile_off(b, pz >> 3) + (pz & 7) * 2) = (int16_t)jpegx_clamp_i16(r);
         }
-        const double y = coop_fwd_exact(a, sA, sM, lane);
-        const double r = jpegx_quant_ref(y, lane, prm.mode, prm.param, c_rq64.v);
-        const int pz = c_zzinv.v[lane];
-        *reinterpret_cast<int16_t *>(lds + tile_off(b, pz >> 3) + (pz & 7) * 2) = (int16_t)jpegx_clamp_i16(r);
     }
     __syncthreads();
 
@@ -295,6 +302,8 @@ __device__ __forceinline__ void forward_strip_body(unsigned char *lds, int wg, c
     unsigned long long flagged = __ballot(valid && !(worst < 0.5f));
     census(counters, flagged, nblk - g0, lane);
     if (prm.tune & 1) flagged = 0;
+    const double rq_lane = flagged ? c_rq64.v[lane] : 0.0;   // once per wave, not once per flagged block
+    const int pz_lane = flagged ? c_zzinv.v[lane] : 0;
     while (flagged) {   // exact tier, inputs re-read from the strip still resident in LDS
         const int b = __ffsll((long long)flagged) - 1;
         flagged &= flagged - 1;
@@ -302,8 +311,8 @@ __device__ __forceinline__ void forward_strip_body(unsigned char *lds, int wg, c
         const int fb = ((b >> 2) ^ (b >> 3)) & 1;
         const float x = *reinterpret_cast<const float *>(lds + i * 2048 + ((2 * b + ((j >> 2) ^ fb)) << 4) + (j & 3) * 4);
         const double y = coop_fwd_exact((double)x, sA, sM, lane);
-        const double r = jpegx_quant_ref(y, lane, prm.mode, prm.param, c_rq64.v);
-        sP[c_zzinv.v[lane]] = (int16_t)jpegx_clamp_i16(r);
+        const double r = jpegx_quant_lane(y, lane, prm.mode, prm.param, rq_lane);
+        sP[pz_lane] = (int16_t)jpegx_clamp_i16(r);
         __syncthreads();
         if (lane == b) {
 #pragma unroll
@@ -330,7 +339,16 @@ __global__ __launch_bounds__(64) void k_forward_fused_strip(const float *__restr
                                                             unsigned long long *counters)
 {
     __shared__ __attribute__((aligned(16))) unsigned char lds[STRIP_LDS_BYTES];
-    forward_strip_body<VAR, NT>(lds, blockIdx.x, in, pitch, wb, nblk, prm, out, counters);
+    int wg = blockIdx.x;
+    if (prm.tune & 2) {
+        // XCD-contiguous order: workgroups are dealt round-robin over the 8 XCDs, so workgroup i of XCD
+        // (i % 8) takes strip (i % 8) * chunk + i / 8 -- every XCD then walks its own contiguous eighth of
+        // the planes and a 2 MiB page is touched (and translated) by one XCD instead of all eight
+        const int nwg = (nblk + 63) >> 6, chunk = (nwg + 7) >> 3;
+        wg = (int)(blockIdx.x & 7u) * chunk + (int)(blockIdx.x >> 3);
+        if (wg >= nwg) return;
+    }
+    forward_strip_body<VAR, NT>(lds, wg, in, pitch, wb, nblk, prm, out, counters);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -846,12 +864,20 @@ int launch_forward(const float *d_in, int H, int W, ptrdiff_t pitch, const Quant
         else
             hipLaunchKernelGGL((k_forward_fused_wpb<0, NT>), grid, block, 0, st, d_in, (size_t)pitch, wb, nblk, qp, d_out, g_counters);
     } else if (BS == 1 && !(flags & JPEGX_F_TUNE_NO_STRIP)) {
+        QuantParams q2 = qp;
+        dim3 g2 = grid;
+        // measured on MI355X (profiles/r02_ab_xcd_order.txt): +6.5 % at 1024 planes (96 GiB), +8.6 % at 256,
+        // break-even near 64 planes, -3 % at 16 planes -- so it is applied to launches of 2^24 blocks and more
+        if ((flags & JPEGX_F_TUNE_XCD_CONTIG) || (nblk >= (1 << 24) && !(flags & JPEGX_F_TUNE_NO_XCD_CONTIG))) {
+            q2.tune |= 2;
+            g2 = dim3(((grid.x + 7) / 8) * 8);
+        }
         if (dc_exact)
-            hipLaunchKernelGGL((k_forward_fused_strip<3, NT>), grid, block, 0, st, d_in, (size_t)pitch, wb, nblk, qp, d_out, g_counters);
+            hipLaunchKernelGGL((k_forward_fused_strip<3, NT>), g2, block, 0, st, d_in, (size_t)pitch, wb, nblk, q2, d_out, g_counters);
         else if (pixel)
-            hipLaunchKernelGGL((k_forward_fused_strip<1, NT>), grid, block, 0, st, d_in, (size_t)pitch, wb, nblk, qp, d_out, g_counters);
+            hipLaunchKernelGGL((k_forward_fused_strip<1, NT>), g2, block, 0, st, d_in, (size_t)pitch, wb, nblk, q2, d_out, g_counters);
         else
-            hipLaunchKernelGGL((k_forward_fused_strip<0, NT>), grid, block, 0, st, d_in, (size_t)pitch, wb, nblk, qp, d_out, g_counters);
+            hipLaunchKernelGGL((k_forward_fused_strip<0, NT>), g2, block, 0, st, d_in, (size_t)pitch, wb, nblk, q2, d_out, g_counters);
     } else if (dc_exact)
         hipLaunchKernelGGL((k_forward_fused<3, BS, NT, STAGED>), grid, block, 0, st, d_in, (size_t)pitch, wb, nblk, qp, d_out, g_counters);
     else if (pixel)

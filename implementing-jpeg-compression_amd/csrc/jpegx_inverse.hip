@@ -210,7 +210,13 @@ __global__ __launch_bounds__(64) void k_inverse_fused(const int16_t *__restrict_
     unsigned char *xch = lds + TILE_BYTES;
 
     const int lane = threadIdx.x;
-    const int g0 = blockIdx.x * 64;
+    int wg = blockIdx.x;
+    if (prm.tune & 2) {   // XCD-contiguous order for very large launches (see k_forward_fused_strip)
+        const int nwg = (nblk + 63) >> 6, chunk = (nwg + 7) >> 3;
+        wg = (int)(blockIdx.x & 7u) * chunk + (int)(blockIdx.x >> 3);
+        if (wg >= nwg) return;
+    }
+    const int g0 = wg * 64;
     const int g = g0 + lane;
     const bool valid = g < nblk;
 
@@ -356,7 +362,11 @@ static int inverse_common(const int16_t *d_in, int H, int W, int mode, double pa
     if (rc) return rc;
     if (flags & JPEGX_F_TUNE_SKIP_EXACT) qp.tune |= 1;
     const int wb = W / 8, nblk = (H / 8) * wb;
-    const dim3 grid((nblk + 63) / 64), block(64);
+    dim3 grid((nblk + 63) / 64), block(64);
+    if ((flags & JPEGX_F_TUNE_XCD_CONTIG) || (nblk >= (1 << 24) && !(flags & JPEGX_F_TUNE_NO_XCD_CONTIG))) {
+        qp.tune |= 2;
+        grid = dim3(((grid.x + 7) / 8) * 8);
+    }
     const int clamp = (flags & JPEGX_F_CLAMP_U8) ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
     const bool nt = (flags & JPEGX_F_TUNE_NO_NT) == 0;

@@ -186,6 +186,18 @@ JPEGX_HD double jpegx_quant_ref(double a, int n, int mode, double param, const d
     return rint(a);
 }
 
+// the same with the table entry 1.0/q of position n already at hand (the kernels fetch it once per lane)
+JPEGX_HD double jpegx_quant_lane(double a, int n, int mode, double param, double rq_n)
+{
+    if (mode == JPEGX_QM_QTABLE) return rint(a * rq_n);
+    if (mode == JPEGX_QM_DIVIDE) return rint(a / param);
+    if (mode == JPEGX_QM_DISCARD) {
+        const int keep = (int)param;
+        return ((n >> 3) >= keep || (n & 7) >= keep) ? 0.0 : rint(a);
+    }
+    return rint(a);
+}
+
 // quantizers.py:8-9,30-31,51-53 (restore)
 JPEGX_HD double jpegx_restore_ref(double a, int n, int mode, double param, const int *qt)
 {

@@ -27,6 +27,8 @@ F_TUNE_NO_NT = 0x100
 F_TUNE_NO_STRIP = 0x200
 F_TUNE_SKIP_EXACT = 0x400
 F_TUNE_WAVE_PER_BLOCK = 0x800
+F_TUNE_XCD_CONTIG = 0x10000
+F_TUNE_NO_XCD_CONTIG = 0x20000
 OUT_F32, OUT_I16, OUT_U8 = 0, 1, 2
 _OUT_DTYPES = {OUT_F32: np.float32, OUT_I16: np.int16, OUT_U8: np.uint8}
 _OUT_BY_NAME = {"f32": OUT_F32, "i16": OUT_I16, "u8": OUT_U8}
