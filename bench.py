@@ -553,6 +553,60 @@ def gather_legs(args, jpegx, multigpu, ctl, rank, world, spans, in_ptr, out_ptr,
                        "(per-chunk events), until the whole batch's stream sits on rank 0; max over ranks"}
     except Exception as exc:
         gather = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
+        return gather, e2e
+    # The same exchange after the device entropy stage (steps 7+8, jpegx_entropy_*): every rank run-length
+    # codes its stream first, so what crosses xGMI shrinks by the compression ratio.
+    err, comp = None, None
+    try:
+        nblk = planes * (size // 8) ** 2
+        ws = jpegx.DeviceBuffer(int(L.jpegx_entropy_workspace_bytes(nblk)))
+        jpegx.check(L.jpegx_entropy_sizes(out_ptr, nblk, ws.ptr, s_comp), "jpegx_entropy_sizes")
+        tot = ctypes.c_ulonglong(0)
+        jpegx.check(L.jpegx_entropy_total(ws.ptr, ctypes.byref(tot), s_comp), "jpegx_entropy_total")
+        coded = jpegx.DeviceBuffer(max(16, tot.value))
+    except Exception as exc:
+        err = "%s: %s" % (type(exc).__name__, str(exc)[:300])
+    if not ctl.all_ok(err is None):
+        gather["compressed"] = {"error": "setup: %s" % ctl.allgather(err)}
+        return gather, e2e
+    try:
+        sizes_all = ctl.allgather(int(tot.value))
+        recv_sizes = [0 if (r == 0 and not loopback) else sizes_all[r] for r in range(view.world)] if comm.rank == 0 else None
+        if loopback:
+            recv_sizes = [int(tot.value)]
+        landing = jpegx.DeviceBuffer(max(16, sum(recv_sizes))) if comm.rank == 0 else None
+        ev = jpegx.Event()
+
+        def coded_pass():
+            jpegx.check(L.jpegx_entropy_sizes(out_ptr, nblk, ws.ptr, s_comp), "jpegx_entropy_sizes")
+            jpegx.check(L.jpegx_entropy_emit(out_ptr, nblk, ws.ptr, coded.ptr, s_comp), "jpegx_entropy_emit")
+            jpegx.check(L.jpegx_event_record(ev.handle, s_comp), "jpegx_event_record")
+            jpegx.check(L.jpegx_stream_wait_event(s_comm, ev.handle), "jpegx_stream_wait_event")
+            send = 0 if (comm.rank == 0 and not loopback) else int(tot.value)
+            comm.gather_bytes(coded.ptr, send, landing.ptr if landing else None, recv_sizes, None, root=0, stream=s_comm)
+        timed(coded_pass)
+        t_c = timed(coded_pass)
+        ok = True
+        if (rank == 0 and world > 1) or loopback:
+            # rank 1's first plane (loop-back: the rank's own) re-coded here must be the head of what arrived from it
+            p = lo if loopback else spans[1][0]
+            one_in, one_zz = jpegx.DeviceBuffer(size * size * 4), jpegx.DeviceBuffer(plane_out)
+            jpegx.generate_plane_device(one_in.ptr, size, size, args.kind, seed=0, plane=p)
+            jpegx.forward_fused_device(one_in.ptr, size, size, one_zz.ptr, args.mode, args.param, jpegx.F_PIXEL_INPUT)
+            want = np.frombuffer(jpegx.entropy_encode(one_zz.download((plane_out // 128, 64), np.int16)), np.uint8)
+            got = np.empty(want.size, np.uint8)
+            jpegx.check(L.jpegx_memcpy_d2h(got.ctypes.data, landing.ptr, got.nbytes, None), "d2h")
+            jpegx.check(L.jpegx_device_synchronize(), "sync")
+            ok = bool(np.array_equal(got, want))
+        ok = bool(all(ctl.allgather(ok)))
+        into_root_c = sum(sizes_all[1:]) if not loopback else int(tot.value)
+        raw = sum((b - a) for a, b in spans[1:]) * plane_out if not loopback else planes * plane_out
+        gather["compressed"] = {"ms": round(t_c * 1e3, 3), "bytes_into_root": into_root_c,
+                                "ratio_vs_int16_stream": round(raw / max(1, into_root_c), 2), "root_copy_ok": ok,
+                                "what": "each rank entropy-codes its stream on the device (k_rle_sizes + scans + k_rle_emit), then one "
+                                        "grouped send/recv of the coded bytes; time = coding + exchange, max over ranks"}
+    except Exception as exc:
+        gather["compressed"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
     return gather, e2e
 
 
