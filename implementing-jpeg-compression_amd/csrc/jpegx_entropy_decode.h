@@ -1,0 +1,16 @@
+// jpegx_entropy_decode.h -- internal interface between the device entropy decoder's kernels
+// (jpegx_entropy_decode.hip) and the host orchestration that owns the buffers (jpegx_hostpipe.cpp).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace jpegx_decode {
+int levels_for(long long nblocks);
+size_t phase1_bytes(size_t nbytes);                       // workspace of the candidate count
+size_t phase2_bytes(size_t ncand, long long nblocks);     // workspace of everything after it
+// d_bytes: dword aligned, at least 16 zero bytes readable behind the stream
+void enqueue_phase1(const uint8_t *d_bytes, size_t nbytes, void *d_ws1, hipStream_t st);
+void enqueue_phase2(const uint8_t *d_bytes, size_t nbytes, long long nblocks, void *d_ws1, unsigned ncand, void *d_ws2,
+                    int16_t *d_zz, hipStream_t st);
+}  // namespace jpegx_decode

@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "../../include/jpegx.h"
+#include "jpegx_entropy_decode.h"
 
 extern "C" void jpegx_internal_set_error(const char *msg);
 
@@ -214,6 +215,87 @@ int jpegx_host_compress_abort(void)
         pool->mu.unlock();
     }
     return JPEGX_OK;
+}
+
+namespace {
+// bytes already on the device (pool->d_in, padded) -> int16 stream in pool->d_zz; the caller holds the pool
+int decode_on_device(DevicePool *pool, size_t nbytes, long long nblocks)
+{
+    hipStream_t st = pool->stream;
+    int rc;
+    if ((rc = pool->d_ws.ensure(jpegx_decode::phase1_bytes(nbytes))) || (rc = pool->d_zz.ensure((size_t)nblocks * 128))) return rc;
+    jpegx_decode::enqueue_phase1(static_cast<const uint8_t *>(pool->d_in.p), nbytes, pool->d_ws.p, st);
+    unsigned head[4] = {0, 0, 0, 0};
+    HP_TRY(hipMemcpyAsync(head, pool->d_ws.p, 16, hipMemcpyDeviceToHost, st));
+    HP_TRY(hipStreamSynchronize(st));
+    const unsigned ncand = head[0];
+    if (ncand == 0 || (long long)ncand < nblocks) return fail(JPEGX_E_INVALID, "entropy stream holds fewer blocks than the plane has");
+    if ((rc = pool->d_tmp.ensure(jpegx_decode::phase2_bytes(ncand, nblocks)))) return rc;
+    jpegx_decode::enqueue_phase2(static_cast<const uint8_t *>(pool->d_in.p), nbytes, nblocks, pool->d_ws.p, ncand, pool->d_tmp.p,
+                                 static_cast<int16_t *>(pool->d_zz.p), st);
+    HP_TRY(hipGetLastError());
+    return JPEGX_OK;
+}
+
+int decode_status(DevicePool *pool)     // after the stream has been synchronised
+{
+    unsigned head[4] = {0, 0, 0, 0};
+    HP_TRY(hipMemcpy(head, pool->d_ws.p, 16, hipMemcpyDeviceToHost));
+    if (head[1] != 0) return fail(JPEGX_E_INVALID, "entropy stream is not a sequence of well-formed blocks (device decoder)");
+    return JPEGX_OK;
+}
+}  // namespace
+
+// Inverse of jpegx_host_compress_*: the whole decompress_band job for one plane (pipeline/__init__.py:79-88 for
+// transform 'DCT', dct_size 8): bytes up, entropy decoding ON THE DEVICE (jpegx_entropy_decode.hip), fused
+// inverse with clamp and SubSampling.invert, uint8 samples down.  h_out: [H*bs][out_pitch] bytes.
+int jpegx_host_decompress_plane(const uint8_t *h_bytes, size_t nbytes, int H, int W, int bs, int mode, double param,
+                                uint8_t *h_out, ptrdiff_t out_pitch)
+{
+    if (!h_bytes || !h_out) return fail(JPEGX_E_INVALID, "null host pointer");
+    if (H <= 0 || W <= 0 || (H % 8) || (W % 8)) return fail(JPEGX_E_INVALID, "plane height and width must be positive multiples of 8");
+    if (bs != 1 && bs != 2 && bs != 4) return fail(JPEGX_E_UNSUPPORTED, "host_decompress supports block_size 1, 2 and 4");
+    if (nbytes == 0 || nbytes >= 0xFFFFFFF0ull) return fail(JPEGX_E_INVALID, "entropy stream empty or beyond 4 GiB");
+    if (out_pitch < (ptrdiff_t)W * bs || (out_pitch % (bs == 1 ? 8 : 16)) != 0) return fail(JPEGX_E_INVALID, "output pitch too small or misaligned");
+    const long long nblocks = (long long)(H / 8) * (W / 8);
+    DevicePool *pool = nullptr;
+    int rc = current_pool(&pool);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lock(pool->mu);
+    if (!pool->stream && hipStreamCreateWithFlags(&pool->stream, hipStreamNonBlocking) != hipSuccess) return fail(JPEGX_E_HIP, "hipStreamCreate failed");
+    hipStream_t st = pool->stream;
+    const size_t out_bytes = (size_t)H * bs * out_pitch;
+    if ((rc = pool->d_in.ensure(nbytes + 16)) || (rc = pool->d_out.ensure(out_bytes))) return rc;
+    HP_TRY(hipMemsetAsync(static_cast<uint8_t *>(pool->d_in.p) + (nbytes & ~(size_t)3), 0, 16 + (nbytes & 3), st));   // zero tail (whole dwords)
+    HP_TRY(hipMemcpyAsync(pool->d_in.p, h_bytes, nbytes, hipMemcpyHostToDevice, st));
+    if ((rc = decode_on_device(pool, nbytes, nblocks))) return rc;
+    if ((rc = jpegx_inverse_fused_u8_inflated(static_cast<const int16_t *>(pool->d_zz.p), H, W, mode, param, 0, bs,
+                                              static_cast<uint8_t *>(pool->d_out.p), out_pitch, st)))
+        return rc;
+    HP_TRY(hipMemcpyAsync(h_out, pool->d_out.p, out_bytes, hipMemcpyDeviceToHost, st));
+    HP_TRY(hipStreamSynchronize(st));
+    return decode_status(pool);
+}
+
+// bytes -> int16 [nblocks][64] on the device, host arrays in and out (what jpegx_host_entropy_decode does on the CPU)
+int jpegx_host_entropy_decode_gpu(const uint8_t *h_bytes, size_t nbytes, long long nblocks, int16_t *h_zz)
+{
+    if (!h_bytes || !h_zz) return fail(JPEGX_E_INVALID, "null host pointer");
+    if (nblocks <= 0 || nblocks > 0x7FFFFFC0LL) return fail(JPEGX_E_INVALID, "block count must be in 1 .. 2^31-64");
+    if (nbytes == 0 || nbytes >= 0xFFFFFFF0ull) return fail(JPEGX_E_INVALID, "entropy stream empty or beyond 4 GiB");
+    DevicePool *pool = nullptr;
+    int rc = current_pool(&pool);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lock(pool->mu);
+    if (!pool->stream && hipStreamCreateWithFlags(&pool->stream, hipStreamNonBlocking) != hipSuccess) return fail(JPEGX_E_HIP, "hipStreamCreate failed");
+    hipStream_t st = pool->stream;
+    if ((rc = pool->d_in.ensure(nbytes + 16))) return rc;
+    HP_TRY(hipMemsetAsync(static_cast<uint8_t *>(pool->d_in.p) + (nbytes & ~(size_t)3), 0, 16 + (nbytes & 3), st));
+    HP_TRY(hipMemcpyAsync(pool->d_in.p, h_bytes, nbytes, hipMemcpyHostToDevice, st));
+    if ((rc = decode_on_device(pool, nbytes, nblocks))) return rc;
+    HP_TRY(hipMemcpyAsync(h_zz, pool->d_zz.p, (size_t)nblocks * 128, hipMemcpyDeviceToHost, st));
+    HP_TRY(hipStreamSynchronize(st));
+    return decode_status(pool);
 }
 
 // used by host_roundtrip (jpegx_internal.h): the synchronous host-pointer conveniences borrow the pool's

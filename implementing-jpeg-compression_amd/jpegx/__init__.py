@@ -103,6 +103,8 @@ SIGNATURES = {
     "jpegx_host_compress_finish": [_vp],
     "jpegx_host_compress_abort": [],
     "jpegx_host_pool_release": [],
+    "jpegx_host_decompress_plane": [_vp, _sz, _int, _int, _int, _int, _dbl, _vp, _pd],
+    "jpegx_host_entropy_decode_gpu": [_vp, _sz, _c.c_longlong, _vp],
     "jpegx_entropy_workspace_bytes": [_c.c_longlong],
     "jpegx_entropy_sizes": [_vp, _c.c_longlong, _vp, _vp],
     "jpegx_entropy_total": [_vp, _c.POINTER(_c.c_ulonglong), _vp],
@@ -601,6 +603,28 @@ def compress_plane(plane, block_size=1, mode="qtable", param=0.0):
         for b in (din, dzz, dws, dout):
             if b is not None:
                 b.free()
+
+
+def entropy_decode_gpu(blob, nblocks):
+    """bytes -> int16 (nblocks, 64) with the parallel decoder on the device (jpegx_entropy_decode.hip)."""
+    buf = np.frombuffer(bytes(blob), dtype=np.uint8)
+    out = np.empty((int(nblocks), 64), dtype=np.int16)
+    check(lib().jpegx_host_entropy_decode_gpu(buf.ctypes.data if buf.size else None, buf.size, int(nblocks),
+                                              out.ctypes.data), "jpegx_host_entropy_decode_gpu")
+    return out
+
+
+def decompress_plane(blob, height, width, block_size=1, mode="qtable", param=0.0):
+    """Steps 8-1 inverted for one plane, everything on the device: entropy decoding, un-zigzag, dequantise, IDCT,
+    round, clamp, replicate block_size x block_size.  (height, width) = the plane AFTER pooling, multiples of 8.
+    Returns uint8 (height * block_size, width * block_size)."""
+    buf = np.frombuffer(bytes(blob), dtype=np.uint8)
+    bs = int(block_size)
+    pitch = (width * bs + 15) // 16 * 16
+    out = np.empty((height * bs, pitch), dtype=np.uint8)
+    check(lib().jpegx_host_decompress_plane(buf.ctypes.data if buf.size else None, buf.size, int(height), int(width), bs,
+                                            mode_of(mode), float(param), out.ctypes.data, pitch), "jpegx_host_decompress_plane")
+    return out[:, :width * bs]
 
 
 def entropy_decode(blob, nblocks):

@@ -280,6 +280,16 @@ int jpegx_host_compress_begin(const void *h_plane, int elem_size, int H, int W, 
                               int mode, double param, size_t *nbytes);
 int jpegx_host_compress_finish(uint8_t *h_out);
 int jpegx_host_compress_abort(void);
+/* The way back (decompress_band, pipeline/__init__.py:79-88, transform 'DCT', dct_size 8): the band's byte
+ * stream up, RleBytestream.invert + RunLengthEncoding.invert (pipeline/rle_byte_stream.py:61-88,
+ * pipeline/run_length_encoding.py:66-97) ON THE DEVICE -- the stream has no index, block starts are recovered
+ * in parallel from the zero byte every block ends with (csrc/jpegx_entropy_decode.hip) -- then the fused
+ * inverse with clamp and SubSampling.invert; uint8 samples [H*bs][out_pitch] down.  JPEGX_E_INVALID when the
+ * bytes are not H/8 * W/8 well-formed blocks.                                                              */
+int jpegx_host_decompress_plane(const uint8_t *h_bytes, size_t nbytes, int H, int W, int bs, int mode,
+                                double param, uint8_t *h_out, ptrdiff_t out_pitch);
+/* the entropy decoding alone on the device: bytes -> int16 [nblocks][64] (= jpegx_host_entropy_decode) */
+int jpegx_host_entropy_decode_gpu(const uint8_t *h_bytes, size_t nbytes, long long nblocks, int16_t *h_zz);
 /* frees the pooled device / pinned buffers and the pooled stream of the current device */
 int jpegx_host_pool_release(void);
 

@@ -90,3 +90,59 @@ def test_emit_after_a_flagged_sizes_pass_writes_nothing(gpu):
     gpu.check(L.jpegx_entropy_emit(dzz.ptr, 130, dws.ptr, dout.ptr, None))      # enqueues, writes nothing
     gpu.check(L.jpegx_device_synchronize())
     assert np.all(dout.download((130 * 256,), np.uint8) == 0xAB)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_device_entropy_decoder_matches_the_host_parser(gpu, golden, case):
+    """The parallel decoder (block starts recovered from the zero byte that ends every block, pointer doubling,
+    lane-per-block decode) returns exactly what the sequential host parser returns, on every golden stream."""
+    c = golden(case)
+    for suffix, _, _ in MODES:
+        zz = c["zz_" + suffix]
+        blob = oracle.rle_bytestream(zz)
+        n = zz.shape[0] * zz.shape[1]
+        assert np.array_equal(gpu.entropy_decode_gpu(blob, n).reshape(zz.shape), zz), (case, suffix)
+        assert np.array_equal(gpu.entropy_decode(blob, n).reshape(zz.shape), zz)
+
+
+@pytest.mark.parametrize("kind", ["noise", "smooth"])
+def test_device_entropy_decoder_large_and_adversarial(gpu, kind):
+    a = gpu.synth.generate_plane(kind, 2048, 2048, seed=17)
+    for mode, param in (("qtable", 0.0), ("none", 0.0), ("divide", 7.0)):
+        zz = oracle.forward_f32(a, mode, param)
+        blob = oracle.rle_bytestream(zz)
+        assert np.array_equal(gpu.entropy_decode_gpu(blob, zz.shape[0] * zz.shape[1]).reshape(zz.shape), zz), mode
+    rng = np.random.default_rng(5)
+    for nblocks in (1, 2, 63, 64, 65, 1000, 4097):
+        z = (rng.integers(-40, 41, (nblocks, 64)) * (rng.random((nblocks, 64)) < 0.2)).astype(np.int16)
+        z[0, :] = rng.integers(-16383, 16384, 64)               # dense block, maximal amplitudes
+        z[nblocks // 2, :] = 0                                   # an all-zero block: the single byte 0x00
+        # amplitudes whose bits contain whole zero bytes: false block-start candidates inside a block
+        z[-1, ::2] = rng.choice(np.array([-16384 + 256, 8192, 4096, 256, -512], dtype=np.int16), 32)
+        blob = oracle.rle_bytestream(z)
+        assert blob.count(b"\x00") > nblocks or nblocks < 3
+        assert np.array_equal(gpu.entropy_decode_gpu(blob, nblocks), z), nblocks
+    assert np.array_equal(gpu.entropy_decode_gpu(b"\x00" * 300, 300), np.zeros((300, 64), np.int16))
+
+
+def test_device_entropy_decoder_rejects_what_the_host_parser_rejects(gpu):
+    z = np.zeros((4, 64), np.int16)
+    z[:, 3] = 5
+    good = oracle.rle_bytestream(z)
+    assert np.array_equal(gpu.entropy_decode_gpu(good, 4), z)
+    for bad, n in ((good[:-1], 4), (good, 5), (b"\x12", 1), (b"\xf0\xf0\xf0\xf0\xf0\x00", 1), (b"\x30\x00", 1),
+                   (good[:3] + b"\xff" + good[4:], 4)):
+        with pytest.raises(gpu.JpegxError):
+            gpu.entropy_decode_gpu(bad, n)
+        with pytest.raises(gpu.JpegxError):
+            gpu.entropy_decode(bad, n)
+
+
+@pytest.mark.parametrize("bs", [1, 2, 4])
+def test_decompress_plane_all_on_device(gpu, bs):
+    """bytes -> samples without the coefficients ever visiting the host == host parse + fused inverse."""
+    a = gpu.synth.generate_plane("noise", 256 * bs, 512 * bs, seed=8)
+    blob = gpu.compress_plane(a.astype(np.uint8), bs, "qtable")
+    zz = gpu.entropy_decode(blob, 32 * 64).reshape(32, 64, 64)
+    want = gpu.inverse_fused_u8(zz, "qtable", inflate=bs)
+    assert np.array_equal(gpu.decompress_plane(blob, 256, 512, bs, "qtable"), want)
