@@ -240,6 +240,25 @@ def compress_band(a, config):
         raise _bad_rle(exc)
 
 
+def decompress_band_u8(compression_result, config):
+    """decompress_band for callers that want the displayable uint8 samples (what Jpeg.decompress turns the
+    band into anyway, pipeline/__init__.py:119-122): skips the int64 array the reference's API returns --
+    for a 4096x4096 band that conversion alone costs more than the whole device pipeline."""
+    import jpegx
+    a = compression_result
+    if _accelerated(config) and _stock_registry() and isinstance(a, (bytes, bytearray)) and len(a) \
+            and config.block_size in (1, 2, 4):
+        mode, param = config.quantization.gpu_mode()
+        if not (mode == "divide" and abs(param) * 32767 >= 2 ** 24):
+            rle = run_length_encoding.RunLengthEncoding(config)
+            hb, wb = rle._height_in_blocks(), rle._width_in_blocks()
+            try:
+                return jpegx.decompress_plane(a, hb * 8, wb * 8, config.block_size, mode, param)[:config.height, :config.width]
+            except jpegx.JpegxError:
+                pass
+    return decompress_band(compression_result, config).astype(np.uint8)
+
+
 def decompress_band(compression_result, config):
     """Run every registered step backwards (pipeline/__init__.py:79-88)."""
     import jpegx
@@ -304,5 +323,5 @@ class Jpeg:
         from PIL import Image
         config, data = file_format.read_data(bytestream)
         size = (config.height, config.width)
-        planes = [decompress_band(b, config).reshape(size) for b in (data.y, data.cb, data.cr)]
-        return Image.fromarray(np.dstack(planes).astype(np.uint8), mode="YCbCr")
+        planes = [decompress_band_u8(b, config).reshape(size) for b in (data.y, data.cb, data.cr)]
+        return Image.fromarray(np.dstack(planes), mode="YCbCr")

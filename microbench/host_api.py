@@ -34,10 +34,12 @@ def main():
             pipeline.compress_band(band, cfg)                      # warm-up (allocations, clocks)
             tc, blob = best(lambda: pipeline.compress_band(band, cfg))
             td, rec = best(lambda: pipeline.decompress_band(blob, cfg))
+            tu, rec8 = best(lambda: pipeline.decompress_band_u8(blob, cfg))
+            assert np.array_equal(rec8, rec)
             nblk = (size // bs // 8) ** 2
             err = float(np.abs(rec - band64).mean())
-            print("%-6s %-6s block_size %d: compress_band %.2f ms (%.1f Mblocks/s, %d bytes), decompress_band %.1f ms, "
-                  "mean abs error %.2f" % (kind, band.dtype, bs, tc * 1e3, nblk / tc / 1e6, len(blob), td * 1e3, err), flush=True)
+            print("%-6s %-6s block_size %d: compress_band %.2f ms (%.1f Mblocks/s, %d bytes), decompress_band %.1f ms (uint8 result: %.2f ms), "
+                  "mean abs error %.2f" % (kind, band.dtype, bs, tc * 1e3, nblk / tc / 1e6, len(blob), td * 1e3, tu * 1e3, err), flush=True)
 
 
 if __name__ == "__main__":
