@@ -75,6 +75,29 @@ constexpr InvExactTab make_inv_exact_tab()
 }
 static_assert(sizeof(InvExactTab) == 1024, "one DMA instruction = 64 lanes x 16 B");
 __device__ __attribute__((aligned(16))) const InvExactTab c_inv_exact = make_inv_exact_tab();
+// The forward exact tier's tables in one DMA-sized (1 KiB) piece, same idea as InvExactTab: C[k][n], the
+// luminance table (1.0 / q is recomputed in float64 from the byte: the same correctly rounded quotient the
+// host table holds) and the inverse zigzag order.
+struct FwdExactTab {
+    double c[64];
+    unsigned char q[64];
+    unsigned char zzinv[64];
+    unsigned char pad[1024 - 512 - 64 - 64];
+};
+constexpr FwdExactTab make_fwd_exact_tab()
+{
+    FwdExactTab t{};
+    D64 c{{JPEGX_TABLE_DCT_MATRIX}};
+    I64 zi = make_zzinv(), qt = make_qt();
+    for (int n = 0; n < 64; ++n) {
+        t.c[n] = c.v[n];
+        t.q[n] = (unsigned char)qt.v[n];
+        t.zzinv[n] = (unsigned char)zi.v[n];
+    }
+    return t;
+}
+static_assert(sizeof(FwdExactTab) == 1024, "one DMA instruction = 64 lanes x 16 B");
+__device__ __attribute__((aligned(16))) const FwdExactTab c_fwd_exact = make_fwd_exact_tab();
 __device__ const D64 c_rq64 = make_rq64();
 __device__ const I64 c_qt = make_qt();
 __device__ const I64 c_zz = make_zz();
@@ -141,6 +164,20 @@ __device__ __forceinline__ double coop_fwd_exact(double a_own, double *sA, doubl
     sM[lo * 8 + hi] = m;                                              // column l contiguous over i
     __syncthreads();
     const double y = jpegx_dot8_ref(&c_dct[hi * 8], &sM[lo * 8], 1);  // Y[k=hi][l=lo]
+    __syncthreads();
+    return y;
+}
+
+// the same with the matrix rows read from an LDS copy of the table (no vector memory load)
+__device__ __forceinline__ double coop_fwd_exact_tab(double a_own, double *sA, double *sM, int lane, const double *tabC)
+{
+    const int hi = lane >> 3, lo = lane & 7;
+    sA[lane] = a_own;
+    __syncthreads();
+    const double m = jpegx_dot8_ref(&tabC[lo * 8], &sA[hi * 8], 1);  // M[i=hi][l=lo]
+    sM[lo * 8 + hi] = m;
+    __syncthreads();
+    const double y = jpegx_dot8_ref(&tabC[hi * 8], &sM[lo * 8], 1);  // Y[k=hi][l=lo]
     __syncthreads();
     return y;
 }

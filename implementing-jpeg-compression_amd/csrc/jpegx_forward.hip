@@ -29,7 +29,11 @@ namespace {
 template <int BS, int STAGED> struct PooledLds {
     static constexpr int STAGE_BYTES = STAGED * 2 * BS * 1024;                 // staging buffer (0 if not staged)
     static constexpr int FRONT = STAGE_BYTES > TILE_BYTES ? STAGE_BYTES : TILE_BYTES;
-    static constexpr int BYTES = FRONT + SCRATCH_DOUBLES * 8;
+    // staged variants: behind the cooperative scratch, the exact tier's 1 KiB table (by LDS-DMA) and 128 B
+    // through which the owner of a flagged block hands its samples to the wave
+    static constexpr int TAB = FRONT + SCRATCH_DOUBLES * 8;
+    static constexpr int XBLK = TAB + 1024;
+    static constexpr int BYTES = STAGED ? XBLK + 128 : FRONT + SCRATCH_DOUBLES * 8;
 };
 
 // body of one workgroup (= one wave = 64 blocks starting at block 64 * wg of this plane); `lds` is the
@@ -53,6 +57,15 @@ __device__ __forceinline__ void forward_fused_body(unsigned char *lds, int wg, c
     const int by = gc / wb, bx = gc - by * wb;
     const float *src = in + ((size_t)by * 8 * BS) * pitch + (size_t)bx * 8 * BS;
 
+    // Staged variants keep the exact tier free of vector memory loads (under the streaming load such a
+    // load waits for microseconds, see k_inverse_fused): its tables come in by one LDS-DMA instruction here,
+    // and with 8-bit content pooled 2x2 the lane keeps its 64 pooled samples as fp16 (k/4 <= 255 is exact
+    // there) in 32 registers instead of re-reading the 16 x 16 input samples of a flagged block from memory.
+    constexpr bool TABBED = STAGED > 0;
+    constexpr bool STASH = TABBED && PIXEL && BS == 2;
+    if (TABBED)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(reinterpret_cast<const unsigned char *>(&c_fwd_exact) + lane * 16),
+                                         (__attribute__((address_space(3))) void *)(lds + PooledLds<BS, STAGED>::TAB), 16, 0, 0);
     float v[64];
     if (BS == 1) {
 #pragma unroll
@@ -155,6 +168,18 @@ __device__ __forceinline__ void forward_fused_body(unsigned char *lds, int wg, c
         }
     }
 
+    unsigned stash[STASH ? 32 : 1];
+    if (STASH) {
+        typedef __fp16 h16x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int p = 0; p < 32; ++p) {
+            const h16x2 h = __builtin_amdgcn_cvt_pkrtz(v[2 * p], v[2 * p + 1]);
+            stash[p] = __builtin_bit_cast(unsigned, h);
+            // pack HERE: the optimiser would sink the conversions down to their use in the exact tier and
+            // keep all 64 raw samples alive next to the DCT's (164 VGPRs instead of 118)
+            asm volatile("" : "+v"(stash[p]));
+        }
+    }
     float S = 0.f;
     if (!PIXEL) {
 #pragma unroll
@@ -180,7 +205,46 @@ __device__ __forceinline__ void forward_fused_body(unsigned char *lds, int wg, c
     census(counters, flagged, nblk - g0, lane);
     if (prm.tune & 1) flagged = 0;
     __syncthreads();
-    if (flagged) {
+    if (TABBED && flagged) {
+        const unsigned char *tab = lds + PooledLds<BS, STAGED>::TAB;
+        unsigned char *xblk = lds + PooledLds<BS, STAGED>::XBLK;
+        const double *tabC = reinterpret_cast<const double *>(tab);
+        const double rq_lane = 1.0 / (double)tab[512 + lane];          // quantizers.py:49 "1.0 / q", same quotient
+        const int pz = tab[576 + lane];
+        const int i = lane >> 3, j = lane & 7;
+        auto fetch = [&](int b) -> double {                             // variants without the fp16 stash
+            const int gb = g0 + b;
+            const int byb = gb / wb, bxb = gb - byb * wb;
+            const float *p = in + ((size_t)(byb * 8 + i) * BS) * pitch + (size_t)(bxb * 8 + j) * BS;
+            double s = 0.0;  // np.mean: float64 sum then one division (subsampling.py:11)
+#pragma unroll
+            for (int u = 0; u < BS; ++u)
+#pragma unroll
+                for (int w = 0; w < BS; ++w) s += (double)p[(size_t)u * pitch + w];
+            return s / (double)(BS * BS);
+        };
+        double a_next = STASH ? 0.0 : fetch(__ffsll((long long)flagged) - 1);
+        while (flagged) {
+            const int b = __ffsll((long long)flagged) - 1;
+            flagged &= flagged - 1;
+            double a;
+            if (STASH) {
+                if (lane == b) {
+#pragma unroll
+                    for (int c = 0; c < 8; ++c)
+                        *reinterpret_cast<u32x4 *>(xblk + c * 16) = u32x4{stash[4 * c], stash[4 * c + 1], stash[4 * c + 2], stash[4 * c + 3]};
+                }
+                __syncthreads();
+                a = (double)(float)*reinterpret_cast<const __fp16 *>(xblk + lane * 2);   // exact: the pooled sample k/4
+            } else {
+                a = a_next;
+                if (flagged) a_next = fetch(__ffsll((long long)flagged) - 1);
+            }
+            const double y = coop_fwd_exact_tab(a, sA, sM, lane, tabC);
+            const double r = jpegx_quant_lane(y, lane, prm.mode, prm.param, rq_lane);
+            *reinterpret_cast<int16_t *>(lds + tile_off(b, pz >> 3) + (pz & 7) * 2) = (int16_t)jpegx_clamp_i16(r);
+        }
+    } else if (flagged) {
         // Every vector load in here waits behind the wave's neighbours' streaming traffic, so: the lane's
         // quantiser entry is fetched once, and the samples of the NEXT flagged block are requested before
         // the cooperative pass of the current one (one memory round trip per wave instead of one per block).
