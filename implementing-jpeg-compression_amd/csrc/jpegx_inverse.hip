@@ -328,20 +328,21 @@ __global__ __launch_bounds__(64) void k_inverse_fused(const int16_t *__restrict_
         }
         return;
     }
-    // the narrow types store straight from the registers: fold the exact row in first (flagged waves only)
-    if (__any(fixrow >= 0)) fold_fix(v, fix, fixrow);
     if (!valid) return;
     const int by = g / wb, bx = g - by * wb;
     void *base = (OUT == 1)
         ? static_cast<void *>(reinterpret_cast<int16_t *>(outv) + (size_t)by * 8 * opitch + (size_t)bx * 8)
         : static_cast<void *>(reinterpret_cast<unsigned char *>(outv) + (size_t)by * 8 * INF * opitch + (size_t)bx * 8 * INF);
+    // the narrow types store straight from the registers: a lane skips the fast-tier row its exact row
+    // replaces and stores that one afterwards (every byte is written once; predicated stores, no selects)
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
         float x[8];
 #pragma unroll
         for (int c = 0; c < 8; ++c) x[c] = v[r * 8 + c];
-        store_row<OUT, NT, INF>(base, opitch, r, x, clamp);
+        if (r != fixrow) store_row<OUT, NT, INF>(base, opitch, r, x, clamp);
     }
+    if (fixrow >= 0) store_row<OUT, NT, INF>(base, opitch, fixrow, fix, clamp);
 }
 }  // namespace
 
