@@ -259,6 +259,18 @@ __device__ __forceinline__ void census(unsigned long long *counters, unsigned lo
     }
 }
 
+// XCD-private block order.  Workgroups are dealt round-robin over the 8 XCDs, so with the natural numbering
+// every XCD touches -- and translates for itself -- every 2 MiB page of both streams.  Here workgroup i of
+// XCD (i % 8) takes strip ((j >> logr) * 8 + i % 8) << logr | (j & (2^logr - 1)), j = i / 8: the XCDs take
+// turns in runs of 2^logr strips (logr = 7: 2 MiB of fp32 plane per run), so a page belongs to one XCD.
+// logr = 31: one run per XCD (each walks a contiguous eighth).  Measured in profiles/r02_ab_xcd_order.txt.
+__device__ __forceinline__ int xcd_private_wg(unsigned i, int nwg, int logr)
+{
+    const int j = (int)(i >> 3), x = (int)(i & 7u);
+    if (logr >= 31) return x * ((nwg + 7) >> 3) + j;
+    return (((j >> logr) * 8 + x) << logr) + (j & ((1 << logr) - 1));
+}
+
 // chunk permutation of the forward strip / inverse output strip: 16-B chunk c of a 2 KiB row sits at
 // slot c ^ (bit3(c) ^ bit4(c)), which makes a ds_read_b128 / ds_write_b128 at a 32-byte lane stride
 // bank-conflict free

@@ -404,13 +404,9 @@ __global__ __launch_bounds__(64) void k_forward_fused_strip(const float *__restr
 {
     __shared__ __attribute__((aligned(16))) unsigned char lds[STRIP_LDS_BYTES];
     int wg = blockIdx.x;
-    if (prm.tune & 2) {
-        // XCD-contiguous order: workgroups are dealt round-robin over the 8 XCDs, so workgroup i of XCD
-        // (i % 8) takes strip (i % 8) * chunk + i / 8 -- every XCD then walks its own contiguous eighth of
-        // the planes and a 2 MiB page is touched (and translated) by one XCD instead of all eight
-        const int nwg = (nblk + 63) >> 6, chunk = (nwg + 7) >> 3;
-        wg = (int)(blockIdx.x & 7u) * chunk + (int)(blockIdx.x >> 3);
-        if (wg >= nwg) return;
+    if (prm.tune & 2) {   // XCD-private order (jpegx_device.h: xcd_private_wg)
+        wg = xcd_private_wg(blockIdx.x, (nblk + 63) >> 6, (prm.tune >> 8) & 31);
+        if (wg >= ((nblk + 63) >> 6)) return;
     }
     forward_strip_body<VAR, NT>(lds, wg, in, pitch, wb, nblk, prm, out, counters);
 }
@@ -930,12 +926,7 @@ int launch_forward(const float *d_in, int H, int W, ptrdiff_t pitch, const Quant
     } else if (BS == 1 && !(flags & JPEGX_F_TUNE_NO_STRIP)) {
         QuantParams q2 = qp;
         dim3 g2 = grid;
-        // measured on MI355X (profiles/r02_ab_xcd_order.txt): +6.5 % at 1024 planes (96 GiB), +8.6 % at 256,
-        // break-even near 64 planes, -3 % at 16 planes -- so it is applied to launches of 2^24 blocks and more
-        if ((flags & JPEGX_F_TUNE_XCD_CONTIG) || (nblk >= (1 << 24) && !(flags & JPEGX_F_TUNE_NO_XCD_CONTIG))) {
-            q2.tune |= 2;
-            g2 = dim3(((grid.x + 7) / 8) * 8);
-        }
+        q2.tune |= xcd_order_setup(flags, nblk, &g2);
         if (dc_exact)
             hipLaunchKernelGGL((k_forward_fused_strip<3, NT>), g2, block, 0, st, d_in, (size_t)pitch, wb, nblk, q2, d_out, g_counters);
         else if (pixel)

@@ -47,6 +47,25 @@ int check_plane(const void *in, const void *out, int H, int W, ptrdiff_t pitch, 
     return JPEGX_OK;
 }
 
+// Launch geometry of the XCD-private order (xcd_private_wg): default for launches of 2^22 blocks and more
+// (16 planes 4096^2) in runs of 128 strips; JPEGX_F_TUNE_XCD_CONTIG forces it, JPEGX_F_TUNE_NO_XCD_CONTIG
+// forbids it, bits 20..24 of the flags pick another run length (31 = one run per XCD).  Returns the tune bits
+// for QuantParams (0 = natural order) and rounds the grid up to whole runs.
+int xcd_order_setup(unsigned flags, int nblk, dim3 *grid)
+{
+    const bool on = (flags & JPEGX_F_TUNE_XCD_CONTIG) || (nblk >= (1 << 22) && !(flags & JPEGX_F_TUNE_NO_XCD_CONTIG));
+    if (!on) return 0;
+    int logr = (int)((flags >> 20) & 31u);
+    if (logr == 0) logr = 7;
+    if (logr >= 31) {
+        *grid = dim3(((grid->x + 7) / 8) * 8);
+    } else {
+        const unsigned run8 = 8u << logr;
+        *grid = dim3(((grid->x + run8 - 1) / run8) * run8);
+    }
+    return 2 | (logr << 8);
+}
+
 int aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 int is_pow2_float(float f)

@@ -211,10 +211,9 @@ __global__ __launch_bounds__(64) void k_inverse_fused(const int16_t *__restrict_
 
     const int lane = threadIdx.x;
     int wg = blockIdx.x;
-    if (prm.tune & 2) {   // XCD-contiguous order for very large launches (see k_forward_fused_strip)
-        const int nwg = (nblk + 63) >> 6, chunk = (nwg + 7) >> 3;
-        wg = (int)(blockIdx.x & 7u) * chunk + (int)(blockIdx.x >> 3);
-        if (wg >= nwg) return;
+    if (prm.tune & 2) {   // XCD-private order (jpegx_device.h: xcd_private_wg)
+        wg = xcd_private_wg(blockIdx.x, (nblk + 63) >> 6, (prm.tune >> 8) & 31);
+        if (wg >= ((nblk + 63) >> 6)) return;
     }
     const int g0 = wg * 64;
     const int g = g0 + lane;
@@ -364,10 +363,7 @@ static int inverse_common(const int16_t *d_in, int H, int W, int mode, double pa
     if (flags & JPEGX_F_TUNE_SKIP_EXACT) qp.tune |= 1;
     const int wb = W / 8, nblk = (H / 8) * wb;
     dim3 grid((nblk + 63) / 64), block(64);
-    if ((flags & JPEGX_F_TUNE_XCD_CONTIG) || (nblk >= (1 << 24) && !(flags & JPEGX_F_TUNE_NO_XCD_CONTIG))) {
-        qp.tune |= 2;
-        grid = dim3(((grid.x + 7) / 8) * 8);
-    }
+    qp.tune |= xcd_order_setup(flags, nblk, &grid);
     const int clamp = (flags & JPEGX_F_CLAMP_U8) ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
     const bool nt = (flags & JPEGX_F_TUNE_NO_NT) == 0;

@@ -29,6 +29,13 @@ F_TUNE_SKIP_EXACT = 0x400
 F_TUNE_WAVE_PER_BLOCK = 0x800
 F_TUNE_XCD_CONTIG = 0x10000
 F_TUNE_NO_XCD_CONTIG = 0x20000
+
+
+def F_TUNE_XCD_RUN(logr):
+    """JPEGX_F_TUNE_XCD_RUN: run length 2^logr strips of the XCD-private order (31 = one run per XCD)."""
+    return (int(logr) & 31) << 20
+
+
 OUT_F32, OUT_I16, OUT_U8 = 0, 1, 2
 _OUT_DTYPES = {OUT_F32: np.float32, OUT_I16: np.int16, OUT_U8: np.uint8}
 _OUT_BY_NAME = {"f32": OUT_F32, "i16": OUT_I16, "u8": OUT_U8}

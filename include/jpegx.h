@@ -63,8 +63,10 @@ typedef enum jpegx_quant_mode {
 #define JPEGX_F_TUNE_NO_F64_KERNEL 0x8000u /* forward: never pick it (fp32 tier + exact tier always)          */
 #define JPEGX_F_TUNE_POOL_ROWS_LO 0x1000u /* pooled forward: fewer input rows per LDS phase (experiment) */
 #define JPEGX_F_TUNE_POOL_ROWS_HI 0x2000u /* pooled forward: more input rows per LDS phase (experiment)  */
-#define JPEGX_F_TUNE_XCD_CONTIG 0x10000u    /* every XCD walks its own contiguous eighth of the blocks (default for \
-                                              launches of 2^24 blocks and more: far fewer address translations)   */
+#define JPEGX_F_TUNE_XCD_CONTIG 0x10000u    /* XCD-private block order: the XCDs take turns in runs of 128 strips, \
+                                              so a 2 MiB page is touched and translated by ONE XCD (default for   \
+                                              launches of 2^22 blocks and more; forward strip and inverse)        */
+#define JPEGX_F_TUNE_XCD_RUN(logr) (((unsigned)(logr) & 31u) << 20) /* other run length 2^logr; 31 = one run per XCD */
 #define JPEGX_F_TUNE_NO_XCD_CONTIG 0x20000u /* never: plain round-robin order */
 #define JPEGX_F_TUNE_NO_STRIP 0x200u /* forward: per-lane global loads instead of LDS-DMA staging    */
 

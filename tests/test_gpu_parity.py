@@ -185,18 +185,20 @@ def test_forward_tuning_variants_are_bit_identical(gpu, kind, flags):
 
 @pytest.mark.parametrize("shape", [(8, 8), (64, 520), (24, 4104), (1032, 1000)])
 def test_xcd_contiguous_block_order_is_only_an_order(gpu, shape):
-    """JPEGX_F_TUNE_XCD_CONTIG (the order very large launches use by default: XCD x walks the x-th eighth of the
-    blocks) on block counts that are not multiples of 8 workgroups: forward and inverse results are unchanged."""
+    """JPEGX_F_TUNE_XCD_CONTIG (the order launches of 2^22 blocks and more use by default: the XCDs take turns in
+    runs of strips) on block counts that are not multiples of a run: forward and inverse results are unchanged."""
     h, w = shape
     a = gpu.synth.generate_plane("noise", h, w, seed=31)
     want = oracle.forward_f32(a, "qtable")
-    assert np.array_equal(gpu.forward_fused(a, "qtable", flags_extra=gpu.F_TUNE_XCD_CONTIG), want)
     dzz, dout = gpu.DeviceBuffer(want.nbytes), gpu.DeviceBuffer(h * w * 4)
     dzz.upload(want)
-    for ot, dt in ((gpu.OUT_F32, np.float32), (gpu.OUT_I16, np.int16)):
-        gpu.inverse_fused_device(dzz.ptr, h, w, dout.ptr, "qtable", 0.0, gpu.F_TUNE_XCD_CONTIG, out_type=ot)
-        gpu.check(gpu.lib().jpegx_device_synchronize())
-        assert np.array_equal(dout.download((h, w), dt).astype(np.int32), oracle.inverse_i16(want, "qtable"))
+    for run in (0, 1, 3, 31):                         # default run (2^7 strips), 2, 8, one run per XCD
+        flags = gpu.F_TUNE_XCD_CONTIG | gpu.F_TUNE_XCD_RUN(run)
+        assert np.array_equal(gpu.forward_fused(a, "qtable", flags_extra=flags), want), run
+        for ot, dt in ((gpu.OUT_F32, np.float32), (gpu.OUT_I16, np.int16)):
+            gpu.inverse_fused_device(dzz.ptr, h, w, dout.ptr, "qtable", 0.0, flags, out_type=ot)
+            gpu.check(gpu.lib().jpegx_device_synchronize())
+            assert np.array_equal(dout.download((h, w), dt).astype(np.int32), oracle.inverse_i16(want, "qtable")), run
 
 
 def test_device_api_with_pitch_stream_and_events(gpu):
