@@ -1,9 +1,13 @@
-"""Step registry and base class -- the reference's plugin API (reference: pipeline/base.py).
+"""The plugin boundary of the codec (behaviour of the reference's pipeline/base.py).
 
-Every concrete step is a class with a ``step_index`` class attribute; creating the class
-registers it in the module-level ``step_classes`` list, kept sorted by ``step_index``
-(pipeline/base.py:7-31).  ``compress_band`` / ``decompress_band`` walk that list.
+A stage is a class derived from ``AlgorithmStep`` that defines a numeric ``step_index`` in its own body;
+defining it is all it takes to take part: the metaclass files the class into the module-level
+``step_classes`` list, which stays ordered by ``step_index`` (classes with equal indices keep the order
+in which they were defined -- defining a second class with an index that is already taken ADDS a stage,
+it does not replace one).  ``compress_band`` walks the list forwards, ``decompress_band`` backwards.
 """
+import bisect
+
 from util import padded_size, split_into_blocks
 
 step_classes = []
@@ -18,29 +22,20 @@ class MissingStepIndexError(Exception):
 
 
 class Meta(type):
-    """Registers every subclass of AlgorithmStep (pipeline/base.py:7-31)."""
+    """Metaclass of AlgorithmStep: registration happens when the class statement finishes."""
 
-    @staticmethod
-    def validate_index(cls, name, class_dict):
-        if "step_index" not in class_dict:
-            raise MissingStepIndexError(
-                'Class {} has not defined "{}" class attribute'.format(name, "step_index"))
-
-    @staticmethod
-    def sort_classes():
-        step_classes.sort(key=lambda c: c.step_index)
-
-    def __new__(meta, name, bases, class_dict):
-        cls = super().__new__(meta, name, bases, class_dict)
-        if name != "AlgorithmStep":
-            Meta.validate_index(cls, name, class_dict)
-            step_classes.append(cls)
-            Meta.sort_classes()
-        return cls
+    def __init__(cls, name, bases, namespace):
+        super().__init__(name, bases, namespace)
+        if name == "AlgorithmStep":
+            return
+        if "step_index" not in namespace:        # must be stated by the class itself, not inherited
+            raise MissingStepIndexError('Class {} has not defined "{}" class attribute'.format(name, "step_index"))
+        bisect.insort_right(step_classes, cls, key=lambda c: c.step_index)
 
 
 class AlgorithmStep(metaclass=Meta):
-    """One reversible stage of the codec: ``execute`` on the way in, ``invert`` on the way out."""
+    """One reversible stage: ``execute`` on the way in, ``invert`` on the way out; constructed per call
+    with the band's Configuration and otherwise stateless."""
 
     def __init__(self, config):
         self._config = config
@@ -52,18 +47,16 @@ class AlgorithmStep(metaclass=Meta):
         raise NotImplementedError
 
     def calculate_padding(self, factor):
-        """(rows, cols) added when the configured image is padded to a multiple of ``factor``."""
-        h, w = self._config.height, self._config.width
-        return padded_size(h, factor) - h, padded_size(w, factor) - w
+        """(rows, cols) by which the configured image grows when padded to a multiple of ``factor``."""
+        return tuple(padded_size(v, factor) - v for v in (self._config.height, self._config.width))
 
     def blocks(self, a, block_size):
-        """Yield (block, y, x) in the codec's block order: y outer, x inner (pipeline/base.py:58-66)."""
+        """(block, y, x) for every block in the codec's order: rows of blocks top to bottom, left to right."""
         tiles = split_into_blocks(a, block_size)
-        for y in range(a.shape[0] // block_size):
-            for x in range(a.shape[1] // block_size):
-                yield tiles[y, x], y, x
+        for y, x in ((y, x) for y in range(a.shape[0] // block_size) for x in range(a.shape[1] // block_size)):
+            yield tiles[y, x], y, x
 
     def apply_blockwise(self, a, transformation, block_size, res):
-        """res[block] = transformation(block) for every block (pipeline/base.py:68-72)."""
+        """Writes ``transformation(block)`` over every block's place in ``res``."""
         for block, y, x in self.blocks(a, block_size):
             res[y * block_size:(y + 1) * block_size, x * block_size:(x + 1) * block_size] = transformation(block)

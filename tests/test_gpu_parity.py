@@ -297,6 +297,30 @@ def test_batched_launch_equals_per_plane_launches(gpu):
     assert np.array_equal(rec[:n], want)
 
 
+def test_full_scale_batch_in_xcd_private_order_equals_per_plane_launches(gpu):
+    """16 planes 4096x4096 stacked into one launch -- 2^22 blocks, the size from which the XCD-private block order
+    is the default -- against the same planes transformed one by one (natural order), forward and inverse: a
+    size-independent property (blocks never interact) checked at the scale the bench runs at."""
+    n, planes = 4096, 16
+    L = gpu.lib()
+    src, zz, one = gpu.DeviceBuffer(planes * n * n * 4), gpu.DeviceBuffer(planes * n * n * 2), gpu.DeviceBuffer(n * n * 2)
+    rec, rec1 = gpu.DeviceBuffer(planes * n * n), gpu.DeviceBuffer(n * n)
+    for p in range(planes):
+        gpu.generate_plane_device(src.ptr + p * n * n * 4, n, n, "noise", seed=3, plane=p)
+    gpu.forward_fused_device(src.ptr, n * planes, n, zz.ptr, "qtable", 0.0, gpu.F_PIXEL_INPUT)
+    gpu.check(L.jpegx_inverse_fused(zz.ptr, n * planes, n, 3, 0.0, 0, rec.ptr, n, gpu.OUT_U8, None))
+    gpu.check(L.jpegx_device_synchronize())
+    for p in (0, 7, 15):
+        gpu.forward_fused_device(src.ptr + p * n * n * 4, n, n, one.ptr, "qtable", 0.0, gpu.F_PIXEL_INPUT | gpu.F_TUNE_NO_XCD_CONTIG)
+        gpu.check(L.jpegx_inverse_fused(one.ptr, n, n, 3, 0.0, gpu.F_TUNE_NO_XCD_CONTIG, rec1.ptr, n, gpu.OUT_U8, None))
+        gpu.check(L.jpegx_device_synchronize())
+        assert np.array_equal(zz.download((n * n,), np.int16, offset=p * n * n * 2), one.download((n * n,), np.int16)), p
+        assert np.array_equal(rec.download((n * n,), np.uint8, offset=p * n * n), rec1.download((n * n,), np.uint8)), p
+    # and plane 0 of the batch against the oracle
+    want = oracle.forward_f32(gpu.synth.generate_plane("noise", 512, n, seed=3, plane=0), "qtable")
+    assert np.array_equal(zz.download(want.shape, np.int16), want)
+
+
 def test_random_shapes_modes_and_values_against_oracle(gpu):
     """Seeded fuzz: random plane shapes, quantisers, parameters and value ranges (incl. negative and
     fractional fp32 samples, which take the generic non-pixel variant)."""
