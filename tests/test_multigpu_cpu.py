@@ -130,6 +130,18 @@ def test_bench_launches_itself_for_n_ranks(tmp_path):
     assert line["shards"] == [[0, 3], [3, 5]] and line["launcher"] == "jpegx.multigpu.launch_ranks"
 
 
+def test_bench_dry_run_with_eight_ranks(tmp_path):
+    """The driver's largest case as control flow only: 8 ranks, the 1024-plane batch, 128 planes each."""
+    env = dict(os.environ, JPEGX_CTL_DIR=str(tmp_path))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "8", "--dry-run"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    line = _bench_line(res)
+    assert line["n_gpus"] == 8 and line["all_ok"] is True and line["max_rank"] == 7.0
+    assert line["shards"] == [[128 * r, 128 * (r + 1)] for r in range(8)]
+
+
 def test_bench_runs_as_ranks_of_torch_distributed_run(tmp_path):
     """The driver's command for N > 1: torch.distributed.run starts the ranks, bench.py joins as one."""
     port = _free_port()
