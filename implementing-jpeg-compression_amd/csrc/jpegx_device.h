@@ -237,6 +237,39 @@ __device__ __forceinline__ float quantise_zigzag_pack(const float (&v)[64], cons
     return worst;
 }
 
+// The same, keeping the worst margin PER COLUMN l = n % 8 of the block (eight running maxima instead of
+// one: no extra instructions) and returning the set of columns that hold an unsafe coefficient -- the unit
+// of work of the column-wise exact tier (fwd_exact_columns).
+template <bool PIXEL, bool DC_EXACT>
+__device__ __forceinline__ unsigned quantise_zigzag_pack_cols(const float (&v)[64], const QuantParams &prm, float E,
+                                                              unsigned (&pk)[32])
+{
+    float worst[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int p = 0; p < 64; p += 2) {
+        int q[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int n = kZZ.v[p + h];
+            const float rq = prm.rq32[n];
+            const float t = v[n] * rq;
+            const float r = rintf(t);
+            if (!(DC_EXACT && n == 0)) worst[n & 7] = fmaxf(worst[n & 7], fmaf(E, fabsf(rq), fabsf(t - r)));
+            q[h] = (int)r;
+        }
+        if (PIXEL) {
+            pk[p >> 1] = ((unsigned)q[0] & 0xFFFFu) | ((unsigned)q[1] << 16);
+        } else {
+            const int a = min(max(q[0], -32768), 32767), b = min(max(q[1], -32768), 32767);
+            pk[p >> 1] = ((unsigned)a & 0xFFFFu) | ((unsigned)b << 16);
+        }
+    }
+    unsigned mask = 0;
+#pragma unroll
+    for (int l = 0; l < 8; ++l) mask |= (worst[l] < 0.5f) ? 0u : (1u << l);
+    return mask;
+}
+
 // The wave's 64 x 128 B output tile -> 8 coalesced 1 KiB stores into the zigzag stream.
 template <bool NT>
 __device__ __forceinline__ void store_tile(const unsigned char *tile, int16_t *out, int g0, int nblk, int lane)

@@ -412,6 +412,203 @@ __global__ __launch_bounds__(64) void k_forward_fused_strip(const float *__restr
 }
 
 // ------------------------------------------------------------------------------------------------
+// The strip kernel with a COLUMN-WISE exact tier, for quantisers fine enough that many blocks hold an
+// unsafe coefficient (divisors of a few units: 14-33 % of the blocks) but not so many that the all-float64
+// kernel wins.  Same staging, fast tier and write-out as k_forward_fused_strip; what differs:
+//   * the fast tier knows per COLUMN of a block whether one of its coefficients is unsafe
+//     (quantise_zigzag_pack_cols), so the unit of exact work is one column (b, l):
+//     M[i][l] = C[l] . A[i] for the 8 rows, then Y[k][l] = C[k] . M[:, l] for the 8 frequencies -- 16 dots of
+//     length 8 in the reference's order instead of the block's 128;
+//   * eight units per pass, lane (s, t) serving unit s: row t in the first half, frequency t in the second;
+//   * the tier's tables (FwdExactTab) ride into LDS with the strip by a seventeenth DMA instruction and the
+//     samples come from the strip: no vector memory load;
+//   * a unit's 8 exact coefficients travel to the block's owner lane through LDS together with their zigzag
+//     positions; the owner holds up to two units in registers and writes them over its 128 B of the output
+//     tile after parking it (a third unit of the same block first flushes the oldest into the packed registers).
+// ------------------------------------------------------------------------------------------------
+constexpr int CU_TAB = STRIP_BYTES;                 // FwdExactTab: C (512 B), luminance table, inverse zigzag
+constexpr int CU_M = CU_TAB + 1024;                 // 8 slots x 8 doubles
+constexpr int CU_M_STRIDE = 64;
+constexpr int CU_RES = CU_M + 8 * CU_M_STRIDE;      // 8 slots x 8 x {int16 value, uint16 zigzag position}
+constexpr int CU_LDS_BYTES = CU_RES + 8 * 32;       // 18176: nine waves per CU, like the plain strip kernel
+static_assert(CU_LDS_BYTES <= 163840 / 9, "nine waves per CU");
+
+// write one exact column (8 x {value, position}) into the packed coefficient registers (rare: third unit of a block)
+__device__ __forceinline__ void flush_unit_into_pk(unsigned (&pk)[32], const unsigned (&unit)[8])
+{
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const unsigned val = unit[k] & 0xFFFFu, pos = unit[k] >> 16;
+#pragma unroll
+        for (int w = 0; w < 32; ++w) {
+            pk[w] = (pos == 2u * w) ? ((pk[w] & 0xFFFF0000u) | val) : pk[w];
+            pk[w] = (pos == 2u * w + 1u) ? ((pk[w] & 0x0000FFFFu) | (val << 16)) : pk[w];
+        }
+    }
+}
+
+template <int VAR, bool NT>
+__global__ __launch_bounds__(64) void k_forward_fused_strip_cols(const float *__restrict__ in, size_t pitch, int wb,
+                                                                 int nblk, QuantParams prm, int16_t *__restrict__ out,
+                                                                 unsigned long long *counters)
+{
+    constexpr bool PIXEL = (VAR & 1) != 0;
+    constexpr bool DC_EXACT = (VAR & 2) != 0;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[CU_LDS_BYTES];
+    const int lane = threadIdx.x;
+    int wg = blockIdx.x;
+    if (prm.tune & 2) {
+        wg = xcd_private_wg(blockIdx.x, (nblk + 63) >> 6, (prm.tune >> 8) & 31);
+        if (wg >= ((nblk + 63) >> 6)) return;
+    }
+    const int g0 = wg * 64;
+    const bool valid = g0 + lane < nblk;
+    {
+        const float *src[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int c = strip_swz(64 * j + lane);
+            const int gb = min(g0 + (c >> 1), nblk - 1);
+            const int by = gb / wb, bx = gb - by * wb;
+            src[j] = in + (size_t)by * 8 * pitch + (size_t)bx * 8 + (c & 1) * 4;
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src[0] + (size_t)r * pitch),
+                                             (__attribute__((address_space(3))) void *)(lds + r * 2048), 16, 0, NT ? 2 : 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src[1] + (size_t)r * pitch),
+                                             (__attribute__((address_space(3))) void *)(lds + r * 2048 + 1024), 16, 0, NT ? 2 : 0);
+        }
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(reinterpret_cast<const unsigned char *>(&c_fwd_exact) + lane * 16),
+                                         (__attribute__((address_space(3))) void *)(lds + CU_TAB), 16, 0, 0);
+    }
+    __syncthreads();
+
+    float v[64];
+    const int f = ((lane >> 2) ^ (lane >> 3)) & 1;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const f32x4 lo = *reinterpret_cast<const f32x4 *>(lds + r * 2048 + ((2 * lane + f) << 4));
+        const f32x4 hi = *reinterpret_cast<const f32x4 *>(lds + r * 2048 + ((2 * lane + (f ^ 1)) << 4));
+        v[r * 8 + 0] = lo.x; v[r * 8 + 1] = lo.y; v[r * 8 + 2] = lo.z; v[r * 8 + 3] = lo.w;
+        v[r * 8 + 4] = hi.x; v[r * 8 + 5] = hi.y; v[r * 8 + 6] = hi.z; v[r * 8 + 7] = hi.w;
+    }
+    float S = 0.f;
+    if (!PIXEL) {
+#pragma unroll
+        for (int n = 0; n < 64; ++n) S += fabsf(v[n]);
+    }
+    jpegx_dct8x8_f32(v);
+    if (PIXEL) S = v[0];
+    const float E = jpegx_fwd_err_bound(S);
+    unsigned pk[32];
+    unsigned colmask = quantise_zigzag_pack_cols<PIXEL, DC_EXACT>(v, prm, E, pk);
+    if (!valid) colmask = 0;
+    const unsigned long long flagged = __ballot(colmask != 0);
+    census(counters, flagged, nblk - g0, lane);
+    if (prm.tune & 1) colmask = 0;
+
+    // up to two exact columns held by the owner lane: 8 x {int16 value | zigzag position << 16} each
+    unsigned held0[8], held1[8];
+    int nheld = 0;
+    if (flagged && !(prm.tune & 1)) {
+        const int s = lane >> 3, t = lane & 7;
+        const unsigned char *tab = lds + CU_TAB;
+        for (;;) {
+            unsigned long long pend = __ballot(colmask != 0);
+            if (!pend) break;
+            int b = -1, mine = -1;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int bk = pend ? __ffsll((long long)pend) - 1 : -1;
+                pend &= pend - 1;
+                if (k == s) b = bk;
+                if (bk == lane) mine = k;
+            }
+            const int mycol = __ffs((int)colmask) - 1;
+            const int l = __shfl(mycol, b < 0 ? lane : b);       // the unit's column, from its owner
+            if (mine >= 0) colmask &= colmask - 1;
+            if (b >= 0) {
+                // M[t][l] = C[l] . A[t] (row pass, transforms.py:46-58), samples of block b's row t from the strip
+                const int fb = ((b >> 2) ^ (b >> 3)) & 1;
+                const f32x4 lo = *reinterpret_cast<const f32x4 *>(lds + t * 2048 + ((2 * b + fb) << 4));
+                const f32x4 hi = *reinterpret_cast<const f32x4 *>(lds + t * 2048 + ((2 * b + (fb ^ 1)) << 4));
+                const double x[8] = {(double)lo.x, (double)lo.y, (double)lo.z, (double)lo.w, (double)hi.x, (double)hi.y, (double)hi.z, (double)hi.w};
+                double w[8];
+#pragma unroll
+                for (int n = 0; n < 8; n += 2) {
+                    const double2 q = *reinterpret_cast<const double2 *>(tab + l * 64 + n * 8);
+                    w[n] = q.x; w[n + 1] = q.y;
+                }
+                *reinterpret_cast<double *>(lds + CU_M + s * CU_M_STRIDE + t * 8) = jpegx_dot8_ref(w, x, 1);
+            }
+            __syncthreads();
+            if (b >= 0) {
+                // Y[t][l] = C[t] . M[:, l] (column pass), the reference's float64 quantiser, np.round
+                double m[8], w[8];
+#pragma unroll
+                for (int n = 0; n < 8; ++n) m[n] = *reinterpret_cast<const double *>(lds + CU_M + s * CU_M_STRIDE + n * 8);
+#pragma unroll
+                for (int n = 0; n < 8; n += 2) {
+                    const double2 q = *reinterpret_cast<const double2 *>(tab + t * 64 + n * 8);
+                    w[n] = q.x; w[n + 1] = q.y;
+                }
+                const double y = jpegx_dot8_ref(w, m, 1);
+                const int n = t * 8 + l;
+                const double rq = 1.0 / (double)tab[512 + n];               // quantizers.py:49 "1.0 / q": the same quotient
+                const int val = jpegx_clamp_i16(jpegx_quant_lane(y, n, prm.mode, prm.param, rq));
+                const unsigned pos = tab[576 + n];
+                *reinterpret_cast<unsigned *>(lds + CU_RES + s * 32 + t * 4) = ((unsigned)val & 0xFFFFu) | (pos << 16);
+            }
+            __syncthreads();
+            if (__any(mine >= 0 && nheld == 2)) {               // a third column of one block (rare): make room
+                if (mine >= 0 && nheld == 2) {
+                    flush_unit_into_pk(pk, held0);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) held0[k] = held1[k];
+                    nheld = 1;
+                }
+            }
+            if (mine >= 0) {
+                const u32x4 a = *reinterpret_cast<const u32x4 *>(lds + CU_RES + mine * 32);
+                const u32x4 c = *reinterpret_cast<const u32x4 *>(lds + CU_RES + mine * 32 + 16);
+                const unsigned u[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    if (nheld == 0) held0[k] = u[k]; else held1[k] = u[k];
+                }
+                ++nheld;
+            }
+            // the next pass rewrites CU_M only after its own reads of CU_RES ... no hazard: CU_M is read before the
+            // second barrier of this pass and rewritten after it; CU_RES is read here and rewritten only after the
+            // next pass's first barrier
+        }
+    }
+
+    // the strip is dead: its first 8 KiB become the swizzled output tile; exact columns go over the lane's row
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+        *reinterpret_cast<u32x4 *>(lds + tile_off(lane, c)) = u32x4{pk[c * 4 + 0], pk[c * 4 + 1], pk[c * 4 + 2], pk[c * 4 + 3]};
+    if (nheld > 0) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const unsigned pos = held0[k] >> 16;
+            *reinterpret_cast<int16_t *>(lds + tile_off(lane, pos >> 3) + (pos & 7) * 2) = (int16_t)(held0[k] & 0xFFFFu);
+        }
+    }
+    if (nheld > 1) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const unsigned pos = held1[k] >> 16;
+            *reinterpret_cast<int16_t *>(lds + tile_off(lane, pos >> 3) + (pos & 7) * 2) = (int16_t)(held1[k] & 0xFFFFu);
+        }
+    }
+    __syncthreads();
+    store_tile<NT>(lds, out, g0, nblk, lane);
+}
+
+// ------------------------------------------------------------------------------------------------
 // several planes in ONE grid (BASELINE.json configs[2]: Y + Cb + Cr of a 4:2:0 image).  One launch per
 // plane leaves the two 4096-workgroup chroma launches as a single generation of long-lived waves with
 // nothing to overlap their DMA phases with; as one grid the chroma workgroups are dispatched FIRST
@@ -927,6 +1124,17 @@ int launch_forward(const float *d_in, int H, int W, ptrdiff_t pitch, const Quant
         QuantParams q2 = qp;
         dim3 g2 = grid;
         q2.tune |= xcd_order_setup(flags, nblk, &g2);
+        // column-wise exact tier once a sizeable share of the blocks is expected to be flagged
+        if ((flags & JPEGX_F_TUNE_COLUMN_UNITS) || (expected_exact_share(qp) > 0.08 && !(flags & JPEGX_F_TUNE_NO_COLUMN_UNITS))) {
+            if (dc_exact)
+                hipLaunchKernelGGL((k_forward_fused_strip_cols<3, NT>), g2, block, 0, st, d_in, (size_t)pitch, wb, nblk, q2, d_out, g_counters);
+            else if (pixel)
+                hipLaunchKernelGGL((k_forward_fused_strip_cols<1, NT>), g2, block, 0, st, d_in, (size_t)pitch, wb, nblk, q2, d_out, g_counters);
+            else
+                hipLaunchKernelGGL((k_forward_fused_strip_cols<0, NT>), g2, block, 0, st, d_in, (size_t)pitch, wb, nblk, q2, d_out, g_counters);
+            HIP_TRY(hipGetLastError());
+            return JPEGX_OK;
+        }
         if (dc_exact)
             hipLaunchKernelGGL((k_forward_fused_strip<3, NT>), g2, block, 0, st, d_in, (size_t)pitch, wb, nblk, q2, d_out, g_counters);
         else if (pixel)

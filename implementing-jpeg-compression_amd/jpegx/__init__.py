@@ -29,6 +29,8 @@ F_TUNE_SKIP_EXACT = 0x400
 F_TUNE_WAVE_PER_BLOCK = 0x800
 F_TUNE_XCD_CONTIG = 0x10000
 F_TUNE_NO_XCD_CONTIG = 0x20000
+F_TUNE_COLUMN_UNITS = 0x40000
+F_TUNE_NO_COLUMN_UNITS = 0x80000
 
 
 def F_TUNE_XCD_RUN(logr):

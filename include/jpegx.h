@@ -68,6 +68,8 @@ typedef enum jpegx_quant_mode {
                                               launches of 2^22 blocks and more; forward strip and inverse)        */
 #define JPEGX_F_TUNE_XCD_RUN(logr) (((unsigned)(logr) & 31u) << 20) /* other run length 2^logr; 31 = one run per XCD */
 #define JPEGX_F_TUNE_NO_XCD_CONTIG 0x20000u /* never: plain round-robin order */
+#define JPEGX_F_TUNE_COLUMN_UNITS 0x40000u    /* forward: force the strip kernel with the column-wise exact tier     */
+#define JPEGX_F_TUNE_NO_COLUMN_UNITS 0x80000u /* forward: never pick it                                              */
 #define JPEGX_F_TUNE_NO_STRIP 0x200u /* forward: per-lane global loads instead of LDS-DMA staging    */
 
 /* output element type of jpegx_inverse_fused */

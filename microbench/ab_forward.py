@@ -28,6 +28,8 @@ def main():
     ap.add_argument("--out-type", default="f32")
     ap.add_argument("--pool", type=int, default=1, help="forward: fused mean-pool factor (input is pool x larger)")
     ap.add_argument("--u8", action="store_true", help="forward: uint8 input planes (jpegx_forward_fused_u8)")
+    ap.add_argument("--mode", default="qtable", choices=["qtable", "none", "divide", "discard"])
+    ap.add_argument("--param", type=float, default=0.0)
     a = ap.parse_args()
     jpegx.require_device()
     L = jpegx.lib()
@@ -48,18 +50,18 @@ def main():
         for y0 in range(0, H * pool, rows):
             slab = plane_buf.download((rows, W * pool), np.float32, offset=y0 * W * pool * 4).astype(np.uint8)
             u8_buf.upload(slab, offset=y0 * W * pool)
-    jpegx.forward_fused_device(plane_buf.ptr, H, W, zz_buf.ptr, "qtable", 0.0, jpegx.F_PIXEL_INPUT, pool=pool)
+    jpegx.forward_fused_device(plane_buf.ptr, H, W, zz_buf.ptr, a.mode, a.param, jpegx.F_PIXEL_INPUT, pool=pool)
     jpegx.check(L.jpegx_device_synchronize())
     variants = [(v.split("=")[0], int(v.split("=")[1], 0)) for v in a.variants]
     ot = {"f32": 0, "i16": 1, "u8": 2}[a.out_type]
 
     def launch(flags):
         if a.direction == "forward" and a.u8:
-            jpegx.forward_fused_u8_device(u8_buf.ptr, H, W, zz_buf.ptr, "qtable", 0.0, flags & ~1, pool=pool)
+            jpegx.forward_fused_u8_device(u8_buf.ptr, H, W, zz_buf.ptr, a.mode, a.param, flags & ~1, pool=pool)
         elif a.direction == "forward":
-            jpegx.forward_fused_device(plane_buf.ptr, H, W, zz_buf.ptr, "qtable", 0.0, flags, pool=pool)
+            jpegx.forward_fused_device(plane_buf.ptr, H, W, zz_buf.ptr, a.mode, a.param, flags, pool=pool)
         else:
-            jpegx.inverse_fused_device(zz_buf.ptr, H, W, plane_buf.ptr, "qtable", 0.0, flags, out_type=ot)
+            jpegx.inverse_fused_device(zz_buf.ptr, H, W, plane_buf.ptr, a.mode, a.param, flags, out_type=ot)
 
     times = {n: [] for n, _ in variants}
     e0, e1 = jpegx.Event(), jpegx.Event()

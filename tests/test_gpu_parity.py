@@ -201,6 +201,30 @@ def test_xcd_contiguous_block_order_is_only_an_order(gpu, shape):
             assert np.array_equal(dout.download((h, w), dt).astype(np.int32), oracle.inverse_i16(want, "qtable")), run
 
 
+@pytest.mark.parametrize("kind", ["noise", "smooth"])
+def test_column_wise_exact_tier_is_bit_exact(gpu, golden, kind):
+    """k_forward_fused_strip_cols (the default once many blocks are expected to need the float64 tier, forced
+    here for every quantiser): identical to the oracle on planes, on the tie-stress fixture, with and without the
+    pixel promise, on ragged block counts and on blocks where several columns are flagged at once."""
+    F = gpu.F_TUNE_COLUMN_UNITS
+    a = gpu.synth.generate_plane(kind, 1024, 1024, seed=19)
+    for mode, param in (("qtable", 0.0), ("divide", 7.0), ("divide", 3.0), ("divide", 1.5), ("none", 0.0), ("discard", 4.0),
+                        ("divide", -2.5), ("divide", 40.0)):
+        want = oracle.forward_f32(a, mode, param)
+        for pixel in (True, False):
+            got = gpu.forward_fused(a, mode, param, pixel_input=pixel, flags_extra=F | 0x8000)     # 0x8000: never the f64 kernel
+            assert np.array_equal(got, want), (mode, param, pixel)
+    ties = golden("ties128")
+    assert np.array_equal(gpu.forward_fused(ties["pre"].astype(np.float32), "qtable", flags_extra=F), ties["zz_qtable"])
+    assert np.array_equal(gpu.forward_fused(ties["pre"].astype(np.float32), "none", flags_extra=F | 0x8000), ties["zz_none"])
+    rng = np.random.default_rng(3)
+    for h, w in ((8, 8), (24, 520), (64, 4104)):
+        b = (rng.integers(0, 1024, (h, w)) / 4.0).astype(np.float32)
+        assert np.array_equal(gpu.forward_fused(b, "divide", 2.0, flags_extra=F | 0x8000), oracle.forward_f32(b, "divide", 2.0)), (h, w)
+    # and it is what fine quantisers get by default
+    assert np.array_equal(gpu.forward_fused(a, "divide", 7.0), oracle.forward_f32(a, "divide", 7.0))
+
+
 def test_device_api_with_pitch_stream_and_events(gpu):
     """Device-pointer entry points: padded rows (pitch > W), a non-default stream, HIP events."""
     import ctypes
