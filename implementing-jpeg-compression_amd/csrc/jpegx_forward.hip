@@ -1124,8 +1124,9 @@ int launch_forward(const float *d_in, int H, int W, ptrdiff_t pitch, const Quant
         QuantParams q2 = qp;
         dim3 g2 = grid;
         q2.tune |= xcd_order_setup(flags, nblk, &g2);
-        // column-wise exact tier once a sizeable share of the blocks is expected to be flagged
-        if ((flags & JPEGX_F_TUNE_COLUMN_UNITS) || (expected_exact_share(qp) > 0.08 && !(flags & JPEGX_F_TUNE_NO_COLUMN_UNITS))) {
+        // column-wise exact tier once more than ~4 % of the blocks are expected to be flagged (measured: equal at the
+        // JPEG table's 3.5 %, +16 % at divide 20, +25..37 % at divide 12 / 7 / 5 / 3; beyond 35 % the float64 kernel wins)
+        if ((flags & JPEGX_F_TUNE_COLUMN_UNITS) || (expected_exact_share(qp) > 0.04 && !(flags & JPEGX_F_TUNE_NO_COLUMN_UNITS))) {
             if (dc_exact)
                 hipLaunchKernelGGL((k_forward_fused_strip_cols<3, NT>), g2, block, 0, st, d_in, (size_t)pitch, wb, nblk, q2, d_out, g_counters);
             else if (pixel)
