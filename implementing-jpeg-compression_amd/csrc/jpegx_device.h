@@ -208,13 +208,17 @@ __device__ __forceinline__ double coop_inv_exact(double z_own, double *sA, doubl
 
 // Quantise the 64 coefficients of v (natural order) in zigzag order and pack them as int16 pairs
 // (pipeline/quantization.py:8-18 + pipeline/zigzag_order.py:85-99; the zigzag is a compile-time
-// renaming).  Returns the worst rounding margin max(|t - rint(t)| + E / q): the block is safe iff
-// it stays below 1/2.  PIXEL: values provably fit int16, no saturation needed.
+// renaming).  E = u S (jpegx_fwd_err_unit); a coefficient's bound is E F(k, l) / q with F = jpegx_fwd_roundings.
+// Returns the worst rounding margin max(|t - rint(t)| + E F / q): the block is safe iff it stays below 1/2.
+// PIXEL: values provably fit int16, no saturation needed; the row pass's butterfly adds are exact.
 template <bool PIXEL, bool DC_EXACT>
 __device__ __forceinline__ float quantise_zigzag_pack(const float (&v)[64], const QuantParams &prm, float E,
                                                       unsigned (&pk)[32])
 {
     float worst = 0.f;
+    float Ef[15];                       // E = u S (jpegx_fwd_err_unit) times the coefficient's rounding count F(k, l)
+#pragma unroll
+    for (int j = 0; j < 15; ++j) Ef[j] = E * (float)j;
 #pragma unroll
     for (int p = 0; p < 64; p += 2) {
         int q[2];
@@ -224,7 +228,7 @@ __device__ __forceinline__ float quantise_zigzag_pack(const float (&v)[64], cons
             const float rq = prm.rq32[n];
             const float t = v[n] * rq;
             const float r = rintf(t);
-            if (!(DC_EXACT && n == 0)) worst = fmaxf(worst, fmaf(E, fabsf(rq), fabsf(t - r)));
+            if (!(DC_EXACT && n == 0)) worst = fmaxf(worst, fmaf(Ef[jpegx_fwd_roundings(n, PIXEL)], fabsf(rq), fabsf(t - r)));
             q[h] = (int)r;
         }
         if (PIXEL) {
@@ -245,6 +249,9 @@ __device__ __forceinline__ unsigned quantise_zigzag_pack_cols(const float (&v)[6
                                                               unsigned (&pk)[32])
 {
     float worst[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float Ef[15];
+#pragma unroll
+    for (int j = 0; j < 15; ++j) Ef[j] = E * (float)j;
 #pragma unroll
     for (int p = 0; p < 64; p += 2) {
         int q[2];
@@ -254,7 +261,7 @@ __device__ __forceinline__ unsigned quantise_zigzag_pack_cols(const float (&v)[6
             const float rq = prm.rq32[n];
             const float t = v[n] * rq;
             const float r = rintf(t);
-            if (!(DC_EXACT && n == 0)) worst[n & 7] = fmaxf(worst[n & 7], fmaf(E, fabsf(rq), fabsf(t - r)));
+            if (!(DC_EXACT && n == 0)) worst[n & 7] = fmaxf(worst[n & 7], fmaf(Ef[jpegx_fwd_roundings(n, PIXEL)], fabsf(rq), fabsf(t - r)));
             q[h] = (int)r;
         }
         if (PIXEL) {

@@ -188,7 +188,7 @@ __device__ __forceinline__ void forward_fused_body(unsigned char *lds, int wg, c
     jpegx_dct8x8_f32(v);
     if (PIXEL) S = v[0];  // non-negative samples: sum|x| == DC, exact
     // generic pooled input: the fp32 tile sums are themselves rounded (<= BS^2 u each)
-    const float E = jpegx_fwd_err_bound(S) * ((PIXEL || BS == 1) ? 1.0f : 1.0f + (BS * BS) / 16.0f);
+    const float E = jpegx_fwd_err_unit(S) * ((PIXEL || BS == 1) ? 1.0f : 1.0f + (BS * BS) / 16.0f);
 
     // quantise in zigzag order, pack pairs, track the worst rounding margin
     unsigned pk[32];
@@ -358,7 +358,7 @@ __device__ __forceinline__ void forward_strip_body(unsigned char *lds, int wg, c
     }
     jpegx_dct8x8_f32(v);
     if (PIXEL) S = v[0];
-    const float E = jpegx_fwd_err_bound(S);
+    const float E = jpegx_fwd_err_unit(S);
 
     unsigned pk[32];
     const float worst = quantise_zigzag_pack<PIXEL, DC_EXACT>(v, prm, E, pk);
@@ -500,7 +500,7 @@ __global__ __launch_bounds__(64) void k_forward_fused_strip_cols(const float *__
     }
     jpegx_dct8x8_f32(v);
     if (PIXEL) S = v[0];
-    const float E = jpegx_fwd_err_bound(S);
+    const float E = jpegx_fwd_err_unit(S);
     unsigned pk[32];
     unsigned colmask = quantise_zigzag_pack_cols<PIXEL, DC_EXACT>(v, prm, E, pk);
     if (!valid) colmask = 0;
@@ -916,7 +916,7 @@ __global__ __launch_bounds__(64) void k_forward_fused_u8(const unsigned char *__
     }
 
     jpegx_dct8x8_f32(v);
-    const float E = jpegx_fwd_err_bound(v[0]);            // pixel input: sum|x| == DC, exact
+    const float E = jpegx_fwd_err_unit(v[0]);             // pixel input: sum|x| == DC, exact
     unsigned pk[32];
     const float worst = quantise_zigzag_pack<true, DC_EXACT>(v, prm, E, pk);
 

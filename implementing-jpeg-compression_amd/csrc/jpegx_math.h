@@ -118,6 +118,28 @@ JPEGX_HD void jpegx_idct8x8_f32(float (&v)[64])
 // 16 u S = 2^-20 S is used (margin for second-order terms).
 JPEGX_HD float jpegx_fwd_err_bound(float S) { return S * 0x1p-20f; }
 
+// The same bound per coefficient (round 2).  Counting the roundings on the worst term path of output k of
+// one 1-D pass of jpegx_dct8_f32 (butterfly adds, the fp32 rounding of the cosine, mul / fma roundings):
+//   k = 0: 3 (three adds)   k = 4: 5   k = 2, 6: 5   k odd: 6
+// and when the pass's inputs are multiples of 2^-8 below 2^9 (the PIXEL promise: the adds and subtractions
+// of the butterflies are then exact in fp32, sums stay below 2^12 with 2^-8 granularity):
+//   k = 0: 0                k = 4: 2   k = 2, 6: 3   k odd: 5.
+// Coefficient (k, l) goes through the row pass (output index l; exact adds only there, its outputs are
+// arbitrary reals) and the column pass (output index k), each erring by at most (roundings) u S because
+// |C| <= 1 and every intermediate is bounded by the abs sums; the fp32 reciprocal and the product of the
+// quantiser add 2 u S.  So |t32 - t64| <= F(k, l) u S |1/q| with F = n_row(l) + n_col(k) + 2 between 5 and 14
+// (average 10.75 for pixel input) instead of the uniform 16; 2^-10 relative margin covers the O(u^2) terms
+// and the fp32 evaluation of S and of the bound itself.
+constexpr int jpegx_dct8_roundings(int k, bool exact_adds)
+{
+    return k == 0 ? (exact_adds ? 0 : 3) : ((k & 1) ? (exact_adds ? 5 : 6) : (k == 4 ? (exact_adds ? 2 : 5) : (exact_adds ? 3 : 5)));
+}
+constexpr int jpegx_fwd_roundings(int n, bool pixel_input)   // n = k * 8 + l
+{
+    return jpegx_dct8_roundings(n & 7, pixel_input) + jpegx_dct8_roundings(n >> 3, false) + 2;
+}
+JPEGX_HD float jpegx_fwd_err_unit(float S) { return S * 0x1.004p-24f; }   // u S (1 + 2^-10)
+
 // Same for the inverse.  A 1-D inverse pass (jpegx_idct8_f32) scales its k = 0 input by exactly 1/8 (a
 // power of two; that term only meets the 3 roundings of the final additions) and every k >= 1 input by
 // c/4 with |c| <= 1 (<= 6 roundings on its path: the fp32 rounding of the constant, the product, three

@@ -17,7 +17,7 @@ static const int T_ZZ[64] = { JPEGX_TABLE_ZIGZAG8 };
 extern "C" {
 
 // stats[0] = flagged coefficients, stats[1] = blocks with >=1 flag,
-// stats[2] = max |c32-c64| / (2^-24 * S) observed (as double bits in int64), stats[3]=mismatching fast-tier
+// stats[2] = max over coefficients of observed |t32 - t64| / (E F / q), the kernel's per-coefficient bound
 int emul_forward(const float *in, int H, int W, int mode, double param, const float *rq32,
                  int pixel_input, int dc_exact, int16_t *out, float *out_dct32, double *stats)
 {
@@ -39,7 +39,7 @@ int emul_forward(const float *in, int H, int W, int mode, double param, const fl
                 }
             jpegx_dct8x8_f32(v);
             if (pixel_input) S = v[0];
-            const float E = jpegx_fwd_err_bound(S);
+            const float E = jpegx_fwd_err_unit(S);
             // exact tier for everything (for statistics only)
             double m[64], y64[64];
             for (int i = 0; i < 8; ++i)
@@ -51,11 +51,15 @@ int emul_forward(const float *in, int H, int W, int mode, double param, const fl
             for (int p = 0; p < 64; ++p) {
                 int n = T_ZZ[p];
                 if (out_dct32) out_dct32[(size_t)(by * 8 + (n >> 3)) * W + bx * 8 + (n & 7)] = v[n];
-                double ratio = fabs((double)v[n] - y64[n]) / (0x1p-24 * (double)(S > 0 ? S : 1));
-                if (ratio > maxratio) maxratio = ratio;
+                const int F = jpegx_fwd_roundings(n, pixel_input != 0);
+                /* observed |t32 - t64| against the kernel's bound E F |1/q| (the quantiser's own roundings included) */
                 float t = v[n] * rq32[n];
+                double t64 = mode == JPEGX_QM_QTABLE ? y64[n] * rq64[n] : (mode == JPEGX_QM_DIVIDE ? y64[n] / param : y64[n]);
+                double bound = (double)E * F * fabs((double)rq32[n]);
+                double ratio = bound > 0 ? fabs((double)t - t64) / bound : 0.0;
+                if (rq32[n] != 0.f && ratio > maxratio) maxratio = ratio;
                 float r = rintf(t);
-                float g = fmaf(E, fabsf(rq32[n]), fabsf(t - r));
+                float g = fmaf(E * (float)F, fabsf(rq32[n]), fabsf(t - r));
                 int flag = g >= 0.5f;
                 if (dc_exact && n == 0) flag = 0;
                 int res;
