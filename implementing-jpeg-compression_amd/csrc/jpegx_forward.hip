@@ -1076,11 +1076,13 @@ __global__ __launch_bounds__(64) void k_forward_fused_wpb(const float *__restric
 }
 
 // Expected share of blocks that the fp32 tier would hand to the exact tier, for typical 8-bit content
-// (sum|x| ~ 64 * 128): a coefficient is flagged with probability ~ 2 E / q.  Only steers the choice
-// between two kernels that produce identical output.
+// (sum|x| ~ 64 * 128) and the average per-coefficient rounding count of pixel input (10.75, jpegx_math.h):
+// a coefficient is flagged with probability ~ 2 E / q.  Only steers the choice between kernels that produce
+// identical output (measured crossovers, profiles/r02_ab_column_units.txt): whole-block tier below 3 %
+// (JPEG table: 2.5 %), column-wise tier up to 40 % (divisors 25 ... 1.5), all-float64 kernel beyond.
 double expected_exact_share(const QuantParams &qp)
 {
-    const double E = 8192.0 * 0x1p-20;
+    const double E = 8192.0 * 10.75 * 0x1p-24;
     double keep = 1.0;
     for (int n = 0; n < 64; ++n) {
         const double pflag = 2.0 * E * fabs((double)qp.rq32[n]);
@@ -1111,7 +1113,7 @@ int launch_forward(const float *d_in, int H, int W, ptrdiff_t pitch, const Quant
     const bool dc_exact = pixel && is_pow2_float(qp.rq32[0]) &&
                           (qp.mode != JPEGX_Q_DIVIDE || (double)qp.rq32[0] * qp.param == 1.0);
     if (BS == 1 && !(flags & (JPEGX_F_TUNE_WAVE_PER_BLOCK | JPEGX_F_TUNE_NO_STRIP | JPEGX_F_TUNE_NO_F64_KERNEL)) &&
-        ((flags & JPEGX_F_TUNE_F64_KERNEL) || expected_exact_share(qp) > 0.35)) {
+        ((flags & JPEGX_F_TUNE_F64_KERNEL) || expected_exact_share(qp) > 0.40)) {
         hipLaunchKernelGGL((k_forward_fused_strip_f64<NT>), grid, block, 0, st, d_in, (size_t)pitch, wb, nblk, qp, d_out, g_counters);
     } else if (BS == 1 && (flags & JPEGX_F_TUNE_WAVE_PER_BLOCK)) {
         if (dc_exact)
@@ -1124,9 +1126,8 @@ int launch_forward(const float *d_in, int H, int W, ptrdiff_t pitch, const Quant
         QuantParams q2 = qp;
         dim3 g2 = grid;
         q2.tune |= xcd_order_setup(flags, nblk, &g2);
-        // column-wise exact tier once more than ~4 % of the blocks are expected to be flagged (measured: equal at the
-        // JPEG table's 3.5 %, +16 % at divide 20, +25..37 % at divide 12 / 7 / 5 / 3; beyond 35 % the float64 kernel wins)
-        if ((flags & JPEGX_F_TUNE_COLUMN_UNITS) || (expected_exact_share(qp) > 0.04 && !(flags & JPEGX_F_TUNE_NO_COLUMN_UNITS))) {
+        // column-wise exact tier once more than ~3 % of the blocks are expected to be flagged
+        if ((flags & JPEGX_F_TUNE_COLUMN_UNITS) || (expected_exact_share(qp) > 0.03 && !(flags & JPEGX_F_TUNE_NO_COLUMN_UNITS))) {
             if (dc_exact)
                 hipLaunchKernelGGL((k_forward_fused_strip_cols<3, NT>), g2, block, 0, st, d_in, (size_t)pitch, wb, nblk, q2, d_out, g_counters);
             else if (pixel)
