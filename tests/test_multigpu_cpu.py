@@ -86,6 +86,35 @@ def test_own_launcher_and_control_plane(tmp_path):
     assert not [f for f in os.listdir(tmp_path) if f.startswith("jpegx_ctl_")]     # rendezvous files are removed
 
 
+DYING_WORKER = r'''
+import os, sys, time
+sys.path.insert(0, %(pkg)r)
+from jpegx.multigpu import ControlPlane, ControlPlaneError, rank_env
+rank, local_rank, world = rank_env()
+ctl = ControlPlane(timeout=20.0)
+ctl.barrier()
+if rank == 1:
+    os._exit(7)                       # dies without saying goodbye, between two collectives
+t0 = time.time()
+try:
+    ctl.barrier()
+    ctl.barrier()
+except ControlPlaneError:
+    sys.exit(0 if time.time() - t0 < 15 else 5)      # the survivors notice promptly instead of hanging
+sys.exit(4)
+'''
+
+
+def test_a_dead_rank_is_an_error_on_the_others_not_a_hang(tmp_path):
+    import time
+    from jpegx.multigpu import launch_ranks
+    script = _write(tmp_path, "dying_worker.py", DYING_WORKER)
+    t0 = time.time()
+    rc = launch_ranks(3, [script], extra_env={"JPEGX_CTL_DIR": str(tmp_path)}, grace_s=30.0)
+    assert rc == 7                     # the job fails with the dead rank's code; ranks 0 and 2 exited 0 on their own
+    assert time.time() - t0 < 60
+
+
 def test_control_plane_ignores_a_stale_rendezvous_file(tmp_path):
     """A file left behind by an earlier job on the same MASTER_PORT points at a dead port: the ranks
     keep polling until the live rank 0 has replaced it."""
