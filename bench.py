@@ -547,7 +547,8 @@ def gather_legs(args, jpegx, multigpu, ctl, rank, world, spans, in_ptr, out_ptr,
             scratch_out.free()
         ok = bool(all(ctl.allgather(ok)))
         gather = {"ms": round(t_g * 1e3, 3), "bytes_into_root": into_root, "GBps_into_root": round(into_root / t_g / 1e9, 2),
-                  "xgmi_bound_GBps": XGMI_ROOT_INGRESS_GBPS, "frac_of_xgmi_bound": round(into_root / t_g / 1e9 / XGMI_ROOT_INGRESS_GBPS, 4),
+                  "xgmi_bound_GBps": XGMI_ROOT_INGRESS_GBPS,
+                  "frac_of_xgmi_bound": None if loopback else round(into_root / t_g / 1e9 / XGMI_ROOT_INGRESS_GBPS, 4),
                   "rccl_ranks_reported": counts, "chunk_planes": args.gather_chunk, "rounds": view.rounds, "root_copy_ok": ok,
                   "transport": "loop-back rehearsal on one GPU (1-rank communicator per process)" if loopback else
                                "jpegx_comm_gather_bytes: grouped ncclSend/ncclRecv of raw bytes, comm stream only, data already computed"}

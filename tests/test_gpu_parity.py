@@ -423,6 +423,59 @@ def test_overlapped_transform_and_gather_loopback(gpu):
         gpu.check(L.jpegx_stream_destroy(s2.value))
 
 
+def test_gather_bookkeeping_of_a_three_rank_world_on_one_gpu(gpu):
+    """transform_and_gather's N > 1 branch (what each rank sends in which round, where the root lands it, the
+    root's own planes written in place) with the ranks played one after another on this GPU and a recording
+    stand-in for the communicator that performs the matched transfers as device copies afterwards: the root's
+    buffer must be the un-sharded batch's stream.  Uneven shards (7 planes over 3 ranks), chunk of 2."""
+    from jpegx import multigpu
+    n, total, world, chunk = 256, 7, 3, 2
+    L = gpu.lib()
+    plane_in, plane_out = n * n * 4, n * n * 2
+    plan = multigpu.GatherPlan(total, world, plane_out, chunk)
+    root_buf = gpu.DeviceBuffer(total * plane_out)
+    gpu.check(L.jpegx_memset(root_buf.ptr, 0xEE, total * plane_out, None))
+    calls = {}                                           # (rank, round) -> recorded gather_bytes arguments
+
+    class Recorder:
+        def __init__(self, rank):
+            self.rank, self.nranks, self.round = rank, world, 0
+
+        def gather_bytes(self, send_ptr, send_bytes, recv_ptr=None, recv_bytes=None, recv_offsets=None, root=0, stream=None):
+            calls[(self.rank, self.round)] = (send_ptr, int(send_bytes), recv_ptr, list(recv_bytes), list(recv_offsets), root)
+            self.round += 1
+
+    keep = []
+    for rank in range(world):
+        lo, hi = plan.spans[rank]
+        src = gpu.DeviceBuffer(max(1, hi - lo) * plane_in)
+        for p in range(lo, hi):
+            gpu.generate_plane_device(src.ptr + (p - lo) * plane_in, n, n, "noise", seed=4, plane=p)
+        if rank == 0:
+            stream_ptr = root_buf.ptr + lo * plane_out               # the root's planes are written in place
+        else:
+            own = gpu.DeviceBuffer(max(1, hi - lo) * plane_out)
+            keep.append(own)
+            stream_ptr = own.ptr
+        keep.append(src)
+        events = [gpu.Event() for _ in range(plan.rounds)]
+        multigpu.transform_and_gather(Recorder(rank), plan, src.ptr, stream_ptr, root_buf.ptr if rank == 0 else None, n,
+                                      "qtable", 0.0, gpu.F_PIXEL_INPUT, None, None, events, root=0)
+    gpu.check(L.jpegx_device_synchronize())
+    for k in range(plan.rounds):                          # what RCCL would do with each grouped round
+        _, root_send, recv_ptr, sizes, offs, _ = calls[(0, k)]
+        assert root_send == 0 and sizes[0] == 0           # the root ships nothing to itself
+        for r in range(1, world):
+            send_ptr, send_bytes = calls[(r, k)][:2]
+            assert send_bytes == sizes[r]                 # sender and root agree on the size of the message
+            if send_bytes:
+                gpu.check(L.jpegx_memcpy_d2d(recv_ptr + offs[r], send_ptr, send_bytes, None))
+    gpu.check(L.jpegx_device_synchronize())
+    got = root_buf.download((total, n // 8, n // 8, 64), np.int16)
+    for p in range(total):
+        assert np.array_equal(got[p], oracle.forward_f32(gpu.synth.generate_plane("noise", n, n, seed=4, plane=p), "qtable")), p
+
+
 @pytest.mark.parametrize("kind", ["noise", "smooth"])
 def test_planes_in_one_launch_match_the_oracle(gpu, kind):
     """jpegx_forward_fused_planes (configs[2] layout, reduced size): a bs = 1 plane, two 2x2-pooled planes and
