@@ -66,7 +66,7 @@ struct DevicePool {
     std::mutex mu;                // one host job at a time per device
     hipStream_t stream = nullptr;
     Span d_in, d_zz, d_ws, d_out, d_tmp;
-    Span h_in{nullptr, 0, true};
+    Span h_in{nullptr, 0, true}, h_out{nullptr, 0, true};
     // state between jpegx_host_compress_begin and _finish (the pool stays locked in between)
     bool open = false;
     size_t out_bytes = 0;
@@ -277,6 +277,46 @@ int jpegx_host_decompress_plane(const uint8_t *h_bytes, size_t nbytes, int H, in
     return decode_status(pool);
 }
 
+// The same, handing back what the reference's decompress_band returns: a [rows][cols] int64 array (the band
+// cropped to its configured size).  The uint8 samples come down into pinned staging memory and are widened
+// by a few host threads -- NumPy's astype(int) on a 4096 x 4096 band costs more than the device pipeline.
+int jpegx_host_decompress_plane_i64(const uint8_t *h_bytes, size_t nbytes, int H, int W, int bs, int mode, double param,
+                                    int64_t *h_out, int rows, int cols)
+{
+    if (!h_out || rows <= 0 || cols <= 0 || rows > H * bs || cols > W * bs) return fail(JPEGX_E_INVALID, "bad output shape");
+    const ptrdiff_t pitch = ((ptrdiff_t)W * bs + 15) / 16 * 16;
+    const size_t stage_bytes = (size_t)H * bs * pitch;
+    DevicePool *pool = nullptr;
+    int rc = current_pool(&pool);
+    if (rc) return rc;
+    uint8_t *stage = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(pool->mu);
+        if ((rc = pool->h_out.ensure(stage_bytes))) return rc;
+        stage = static_cast<uint8_t *>(pool->h_out.p);
+    }
+    // (the staging span is only ever touched under the pool mutex or, as below, by the thread that just filled it:
+    // one host job per device at a time is the pool's contract)
+    if ((rc = jpegx_host_decompress_plane(h_bytes, nbytes, H, W, bs, mode, param, stage, pitch))) return rc;
+    const unsigned hw = std::thread::hardware_concurrency();
+    const int nthreads = ((size_t)rows * cols < (1u << 20)) ? 1 : (hw >= 8 ? 8 : (hw ? (int)hw : 1));
+    auto work = [&](int y0, int y1) {
+        for (int y = y0; y < y1; ++y) {
+            const uint8_t *srow = stage + (size_t)y * pitch;
+            int64_t *drow = h_out + (size_t)y * cols;
+            for (int x = 0; x < cols; ++x) drow[x] = srow[x];
+        }
+    };
+    if (nthreads == 1) {
+        work(0, rows);
+    } else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < nthreads; ++t) th.emplace_back(work, (int)((long long)rows * t / nthreads), (int)((long long)rows * (t + 1) / nthreads));
+        for (auto &t : th) t.join();
+    }
+    return JPEGX_OK;
+}
+
 // bytes -> int16 [nblocks][64] on the device, host arrays in and out (what jpegx_host_entropy_decode does on the CPU)
 int jpegx_host_entropy_decode_gpu(const uint8_t *h_bytes, size_t nbytes, long long nblocks, int16_t *h_zz)
 {
@@ -333,7 +373,7 @@ int jpegx_host_pool_release(void)
     int rc = current_pool(&pool);
     if (rc) return rc;
     std::lock_guard<std::mutex> lock(pool->mu);
-    for (Span *s : {&pool->d_in, &pool->d_zz, &pool->d_ws, &pool->d_out, &pool->d_tmp, &pool->h_in}) {
+    for (Span *s : {&pool->d_in, &pool->d_zz, &pool->d_ws, &pool->d_out, &pool->d_tmp, &pool->h_in, &pool->h_out}) {
         if (s->p) { if (s->pinned) (void)hipHostFree(s->p); else (void)hipFree(s->p); }
         s->p = nullptr;
         s->cap = 0;

@@ -113,6 +113,7 @@ SIGNATURES = {
     "jpegx_host_compress_abort": [],
     "jpegx_host_pool_release": [],
     "jpegx_host_decompress_plane": [_vp, _sz, _int, _int, _int, _int, _dbl, _vp, _pd],
+    "jpegx_host_decompress_plane_i64": [_vp, _sz, _int, _int, _int, _int, _dbl, _vp, _int, _int],
     "jpegx_host_entropy_decode_gpu": [_vp, _sz, _c.c_longlong, _vp],
     "jpegx_entropy_workspace_bytes": [_c.c_longlong],
     "jpegx_entropy_sizes": [_vp, _c.c_longlong, _vp, _vp],
@@ -634,6 +635,16 @@ def decompress_plane(blob, height, width, block_size=1, mode="qtable", param=0.0
     check(lib().jpegx_host_decompress_plane(buf.ctypes.data if buf.size else None, buf.size, int(height), int(width), bs,
                                             mode_of(mode), float(param), out.ctypes.data, pitch), "jpegx_host_decompress_plane")
     return out[:, :width * bs]
+
+
+def decompress_plane_i64(blob, height, width, block_size, mode, param, rows, cols):
+    """decompress_plane as the (rows, cols) int64 band the reference's decompress_band returns."""
+    buf = np.frombuffer(bytes(blob), dtype=np.uint8)
+    out = np.empty((int(rows), int(cols)), dtype=np.int64)
+    check(lib().jpegx_host_decompress_plane_i64(buf.ctypes.data if buf.size else None, buf.size, int(height), int(width),
+                                                int(block_size), mode_of(mode), float(param), out.ctypes.data, int(rows), int(cols)),
+          "jpegx_host_decompress_plane_i64")
+    return out
 
 
 def entropy_decode(blob, nblocks):

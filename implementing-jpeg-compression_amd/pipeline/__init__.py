@@ -274,8 +274,9 @@ def decompress_band(compression_result, config):
                 if config.block_size in (1, 2, 4) and len(a) and not (mode == "divide" and abs(param) * 32767 >= 2 ** 24):
                     # all nine steps inverted on the device, entropy decoding included; only the samples come back
                     try:
-                        full = jpegx.decompress_plane(a, hb * 8, wb * 8, config.block_size, mode, param)
-                        return full[:config.height, :config.width].astype(int)
+                        band = jpegx.decompress_plane_i64(a, hb * 8, wb * 8, config.block_size, mode, param,
+                                                          config.height, config.width)
+                        return band if band.dtype == np.dtype(int) else band.astype(int)
                     except jpegx.JpegxError:
                         pass        # not a well-formed stream: the host parser below says exactly what is wrong
                 # entropy stage inverted on the host by libjpegx's C++ parser (steps 8, 7)

@@ -292,6 +292,10 @@ int jpegx_host_compress_abort(void);
  * bytes are not H/8 * W/8 well-formed blocks.                                                              */
 int jpegx_host_decompress_plane(const uint8_t *h_bytes, size_t nbytes, int H, int W, int bs, int mode,
                                 double param, uint8_t *h_out, ptrdiff_t out_pitch);
+/* the same, as the int64 [rows][cols] array decompress_band returns (cropped to the band's configured size;
+ * rows <= H*bs, cols <= W*bs): samples staged in pinned memory and widened by a few host threads          */
+int jpegx_host_decompress_plane_i64(const uint8_t *h_bytes, size_t nbytes, int H, int W, int bs, int mode,
+                                    double param, int64_t *h_out, int rows, int cols);
 /* the entropy decoding alone on the device: bytes -> int16 [nblocks][64] (= jpegx_host_entropy_decode) */
 int jpegx_host_entropy_decode_gpu(const uint8_t *h_bytes, size_t nbytes, long long nblocks, int16_t *h_zz);
 /* frees the pooled device / pinned buffers and the pooled stream of the current device */
