@@ -738,6 +738,167 @@ __global__ __launch_bounds__(64) void k_forward_fused_strip_f64(const float *__r
 }
 
 // ------------------------------------------------------------------------------------------------
+// all-float64 forward, EIGHT LANES PER BLOCK.  The lane-per-block form above keeps a whole block per lane
+// (~200 VGPRs, two waves per SIMD) and its fp64 pipe idles half the time waiting on itself.  Here a wave
+// works on 8 blocks at a time and a lane owns one ROW of its block in the row pass (8 conversions, 8 dot
+// products M[i][0..7]), hands the row to the block's other lanes through LDS, and owns one COLUMN in the
+// column pass (8 dot products Y[0..7][l], quantised and dropped at their zigzag positions in a 1 KiB LDS
+// tile that leaves as one 16-byte store per lane).  Every product and sum is the same float64 operation
+// in the same order as before (jpegx_dot8_ref = transforms.py:36-38 through OpenBLAS) -- only which lane
+// does it changes -- so the results stay bit-exact by construction, at ~40 VGPRs and 4 waves per SIMD.
+// ------------------------------------------------------------------------------------------------
+#ifndef JPEGX_F8_BLOCKS
+#define JPEGX_F8_BLOCKS 16
+#endif
+constexpr int F8_BLOCKS = JPEGX_F8_BLOCKS;                     // blocks per workgroup (one wave), in passes of 8
+constexpr int F8_ROW = F8_BLOCKS * 32;            // bytes of one sample row of the wave's blocks
+constexpr int F8_MSTRIDE = 576;                   // M buffer: 64 doubles per block + 64 B so that blocks spread over the banks
+constexpr int F8_STRIP = 8 * F8_ROW;               // fp32 input only
+
+struct ZigzagColumns { unsigned long long v[8]; };     // v[k] byte l = zigzag position of coefficient (k, l)
+constexpr ZigzagColumns make_zigzag_columns()
+{
+    ZigzagColumns z{};
+    constexpr I64 zi = make_zzinv();
+    for (int k = 0; k < 8; ++k)
+        for (int l = 0; l < 8; ++l) z.v[k] |= (unsigned long long)zi.v[k * 8 + l] << (8 * l);
+    return z;
+}
+
+template <typename T, bool NT>
+__global__ __launch_bounds__(64) void k_forward_fused_f64x8(const T *__restrict__ in, size_t pitch, int wb, int nblk,
+                                                            QuantParams prm, int16_t *__restrict__ out,
+                                                            unsigned long long *counters)
+{
+    constexpr bool F32IN = sizeof(T) == 4;              // fp32 planes are staged by LDS-DMA; float64 rows are read directly
+    constexpr int F8_M = F32IN ? F8_STRIP : 0, F8_TILE = F8_M + 8 * F8_MSTRIDE, F8_LDS = F8_TILE + 1024;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[F8_LDS];
+    const int lane = threadIdx.x;
+    const int g0 = blockIdx.x * F8_BLOCKS;
+    if constexpr (F32IN) {
+        // one LDS-DMA instruction brings two sample rows (2 x F8_ROW = 64 lanes x 16 B); the 16-byte chunk
+        // (block c >> 1, half c & 1) of row r sits at position c ^ (r & 1) of its row, which makes the
+        // row-pass reads below conflict free
+        constexpr int CPR = 2 * F8_BLOCKS, RPI = 64 / CPR;          // chunks per row, rows per instruction
+        static_assert(RPI >= 2 && (RPI & 1) == 0, "two or four rows per LDS-DMA instruction");
+        const int pos = lane % CPR, rr = lane / CPR;
+        const int c = pos ^ (rr & 1);
+        const int gb = min(g0 + (c >> 1), nblk - 1);
+        const int by = gb / wb, bx = gb - by * wb;
+        const float *src = reinterpret_cast<const float *>(in) + ((size_t)by * 8 + rr) * pitch + (size_t)bx * 8 + (c & 1) * 4;
+#pragma unroll
+        for (int j = 0; j < 8 / RPI; ++j)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + (size_t)(RPI * j) * pitch),
+                                             (__attribute__((address_space(3))) void *)(lds + j * RPI * F8_ROW), 16, 0, NT ? 2 : 0);
+    }
+    const int hi3 = lane >> 3, lo3 = lane & 7;
+    // quantiser table entries of this lane's column (mode 'qtable' only; the other modes are uniform)
+    double rq[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) rq[k] = 0.0;
+    if (prm.mode == JPEGX_QM_QTABLE) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) rq[k] = c_rq64.v[k * 8 + lo3];
+    }
+    if (counters != nullptr && lane == 0) atomicAdd(&counters[1], (unsigned long long)min(F8_BLOCKS, nblk - g0));
+    __syncthreads();
+
+#pragma unroll 1
+    for (int t = 0; t < F8_BLOCKS / 8; ++t) {
+        {
+            // row pass: lane = (row i = hi3, block b = lo3 of this pass)
+            const int i = hi3, b = lo3, c2 = 2 * (8 * t + b);
+            double x[8];
+            if constexpr (F32IN) {
+                const unsigned char *row = lds + i * F8_ROW;
+                const f32x4 lo = *reinterpret_cast<const f32x4 *>(row + (((c2 + 0) ^ (i & 1)) << 4));
+                const f32x4 hi = *reinterpret_cast<const f32x4 *>(row + (((c2 + 1) ^ (i & 1)) << 4));
+                x[0] = (double)lo.x; x[1] = (double)lo.y; x[2] = (double)lo.z; x[3] = (double)lo.w;
+                x[4] = (double)hi.x; x[5] = (double)hi.y; x[6] = (double)hi.z; x[7] = (double)hi.w;
+            } else {
+                const int gb = min(g0 + 8 * t + b, nblk - 1);
+                const int by = gb / wb, bx = gb - by * wb;
+                const double *src = reinterpret_cast<const double *>(in) + ((size_t)by * 8 + i) * pitch + (size_t)bx * 8;
+#pragma unroll
+                for (int n = 0; n < 8; n += 2) {
+                    const double2 t2 = *reinterpret_cast<const double2 *>(src + n);
+                    x[n] = t2.x; x[n + 1] = t2.y;
+                }
+            }
+            unsigned char *mb = lds + F8_M + b * F8_MSTRIDE + (i & 1) * 8;
+#pragma unroll
+            for (int l = 0; l < 8; ++l) {
+                const double m = jpegx_dot8_ref(&c_dct[l * 8], x, 1);                        // M[i][l] = C[l] . A[i]
+                const int f = (l >> 2) | ((b & 1) << 1);
+                *reinterpret_cast<double *>(mb + l * 64 + (((i >> 1) ^ f) << 4)) = m;
+            }
+        }
+        __syncthreads();
+        {
+            // column pass: lane = (block b = hi3 of this pass, column l = lo3)
+            const int b = hi3, l = lo3;
+            const int f = (l >> 2) | ((b & 1) << 1);
+            const unsigned char *mb = lds + F8_M + b * F8_MSTRIDE + l * 64;
+            double m[8];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const double2 t2 = *reinterpret_cast<const double2 *>(mb + ((k ^ f) << 4));
+                m[2 * k] = t2.x; m[2 * k + 1] = t2.y;
+            }
+            unsigned char *tile = lds + F8_TILE + b * 128;
+            constexpr ZigzagColumns zc = make_zigzag_columns();
+            double y[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) y[k] = jpegx_dot8_ref(&c_dct[k * 8], m, 1);          // Y[k][l] = C[k] . M[:, l]
+            // the quantiser (quantizers.py:4-49, = jpegx_quant_lane) once per column, outside the unrolled loops,
+            // so that the eight dot products above are one straight-line stretch of independent float64 chains
+            if (prm.mode == JPEGX_QM_QTABLE) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) y[k] = rint(y[k] * rq[k]);
+            } else if (prm.mode == JPEGX_QM_DIVIDE) {
+                // a / d (true division, quantizers.py:27-28).  For d = +-2^e both a / d and a * (1 / d) are the
+                // correctly rounded value of the same real number, so the multiply is bit-identical and 10x cheaper
+                const unsigned long long pb = (unsigned long long)__double_as_longlong(prm.param);
+                const int ex = (int)((pb >> 52) & 0x7FFu);
+                if ((pb & 0xFFFFFFFFFFFFFull) == 0 && ex > 123 && ex < 1923) {
+                    const double r = 1.0 / prm.param;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) y[k] = rint(y[k] * r);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) y[k] = rint(y[k] / prm.param);
+                }
+            } else if (prm.mode == JPEGX_QM_DISCARD) {
+                const int keep = (int)prm.param;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) y[k] = (k >= keep || l >= keep) ? 0.0 : rint(y[k]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) y[k] = rint(y[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                // jpegx_clamp_i16 with the hardware's saturating conversion (v_cvt_i32_f64 clamps to int32, NaN -> 0)
+                // and one integer median instead of two float64 compares and three selects
+                int q;
+                asm("v_cvt_i32_f64 %0, %1" : "=v"(q) : "v"(y[k]));
+                q = min(max(q, -32768), 32767);
+                const unsigned p = (unsigned)(zc.v[k] >> (8 * l)) & 63u;
+                *reinterpret_cast<int16_t *>(tile + p * 2) = (int16_t)q;
+            }
+        }
+        __syncthreads();
+        {
+            const u32x4 q = *reinterpret_cast<const u32x4 *>(lds + F8_TILE + lane * 16);
+            const int gq = g0 + 8 * t;
+            if (gq + hi3 < nblk) st_u32x4<NT>(reinterpret_cast<unsigned char *>(out) + (size_t)gq * 128 + lane * 16, q);
+        }
+        // the next pass's row pass writes M (read above, before the barrier) and its column pass writes the
+        // tile only after the next barrier, which every lane reaches after its tile read: no further barrier
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // fused forward on a FLOAT64 plane: what step 4 receives when the samples are not exact in fp32 -- the
 // means of SubSampling with block_size 3, 5, 6 ... (pipeline/subsampling.py:9-11: k/9, k/25 ...) or any
 // float64 band a caller passes to BasisChange.  Lane-per-block, everything in float64 in the reference's
@@ -1112,9 +1273,17 @@ int launch_forward(const float *d_in, int H, int W, ptrdiff_t pitch, const Quant
     // DC is an exact integer multiple of 2^-8 and rq[0] a power of two -> DC/q needs no tie check
     const bool dc_exact = pixel && is_pow2_float(qp.rq32[0]) &&
                           (qp.mode != JPEGX_Q_DIVIDE || (double)qp.rq32[0] * qp.param == 1.0);
+    // the all-float64 kernel costs the same whatever the data (0.35 ms per 2^22 blocks; 0.44 ms when it has to
+    // divide by something that is not a power of two): measured crossovers against the column-wise tier
+    // (profiles/r02_ab_f64_eight_lanes.txt) at an expected share of 25 % / 40 %
+    const bool cheap_f64 = qp.mode != JPEGX_Q_DIVIDE || is_pow2_float((float)qp.param);
     if (BS == 1 && !(flags & (JPEGX_F_TUNE_WAVE_PER_BLOCK | JPEGX_F_TUNE_NO_STRIP | JPEGX_F_TUNE_NO_F64_KERNEL)) &&
-        ((flags & JPEGX_F_TUNE_F64_KERNEL) || expected_exact_share(qp) > 0.40)) {
-        hipLaunchKernelGGL((k_forward_fused_strip_f64<NT>), grid, block, 0, st, d_in, (size_t)pitch, wb, nblk, qp, d_out, g_counters);
+        ((flags & JPEGX_F_TUNE_F64_KERNEL) || expected_exact_share(qp) > (cheap_f64 ? 0.25 : 0.40))) {
+        if (flags & JPEGX_F_TUNE_F64_LANE_PER_BLOCK)
+            hipLaunchKernelGGL((k_forward_fused_strip_f64<NT>), grid, block, 0, st, d_in, (size_t)pitch, wb, nblk, qp, d_out, g_counters);
+        else
+            hipLaunchKernelGGL((k_forward_fused_f64x8<float, NT>), dim3((nblk + F8_BLOCKS - 1) / F8_BLOCKS), block, 0, st, d_in, (size_t)pitch, wb,
+                               nblk, qp, d_out, g_counters);
     } else if (BS == 1 && (flags & JPEGX_F_TUNE_WAVE_PER_BLOCK)) {
         if (dc_exact)
             hipLaunchKernelGGL((k_forward_fused_wpb<3, NT>), grid, block, 0, st, d_in, (size_t)pitch, wb, nblk, qp, d_out, g_counters);
@@ -1251,10 +1420,15 @@ int jpegx_forward_fused_f64(const double *d_in, int H, int W, ptrdiff_t pitch, i
     if (rc) return rc;
     const int wb = W / 8, nblk = (H / 8) * wb;
     const dim3 grid((nblk + 63) / 64), block(64);
-    if (flags & JPEGX_F_TUNE_NO_NT)
-        hipLaunchKernelGGL((k_forward_fused_f64in<false>), grid, block, 0, (hipStream_t)stream, d_in, (size_t)pitch, wb, nblk, qp, d_out, g_counters);
-    else
-        hipLaunchKernelGGL((k_forward_fused_f64in<true>), grid, block, 0, (hipStream_t)stream, d_in, (size_t)pitch, wb, nblk, qp, d_out, g_counters);
+    const dim3 grid8((nblk + F8_BLOCKS - 1) / F8_BLOCKS);
+    const bool nt = !(flags & JPEGX_F_TUNE_NO_NT);
+    if (flags & JPEGX_F_TUNE_F64_LANE_PER_BLOCK) {
+        if (nt) hipLaunchKernelGGL((k_forward_fused_f64in<true>), grid, block, 0, (hipStream_t)stream, d_in, (size_t)pitch, wb, nblk, qp, d_out, g_counters);
+        else hipLaunchKernelGGL((k_forward_fused_f64in<false>), grid, block, 0, (hipStream_t)stream, d_in, (size_t)pitch, wb, nblk, qp, d_out, g_counters);
+    } else {
+        if (nt) hipLaunchKernelGGL((k_forward_fused_f64x8<double, true>), grid8, block, 0, (hipStream_t)stream, d_in, (size_t)pitch, wb, nblk, qp, d_out, g_counters);
+        else hipLaunchKernelGGL((k_forward_fused_f64x8<double, false>), grid8, block, 0, (hipStream_t)stream, d_in, (size_t)pitch, wb, nblk, qp, d_out, g_counters);
+    }
     HIP_TRY(hipGetLastError());
     return JPEGX_OK;
 }

@@ -249,8 +249,8 @@ int decode_status(DevicePool *pool)     // after the stream has been synchronise
 // Inverse of jpegx_host_compress_*: the whole decompress_band job for one plane (pipeline/__init__.py:79-88 for
 // transform 'DCT', dct_size 8): bytes up, entropy decoding ON THE DEVICE (jpegx_entropy_decode.hip), fused
 // inverse with clamp and SubSampling.invert, uint8 samples down.  h_out: [H*bs][out_pitch] bytes.
-int jpegx_host_decompress_plane(const uint8_t *h_bytes, size_t nbytes, int H, int W, int bs, int mode, double param,
-                                uint8_t *h_out, ptrdiff_t out_pitch)
+static int decompress_plane_locked(DevicePool *pool, const uint8_t *h_bytes, size_t nbytes, int H, int W, int bs, int mode,
+                                   double param, uint8_t *h_out, ptrdiff_t out_pitch)
 {
     if (!h_bytes || !h_out) return fail(JPEGX_E_INVALID, "null host pointer");
     if (H <= 0 || W <= 0 || (H % 8) || (W % 8)) return fail(JPEGX_E_INVALID, "plane height and width must be positive multiples of 8");
@@ -258,10 +258,7 @@ int jpegx_host_decompress_plane(const uint8_t *h_bytes, size_t nbytes, int H, in
     if (nbytes == 0 || nbytes >= 0xFFFFFFF0ull) return fail(JPEGX_E_INVALID, "entropy stream empty or beyond 4 GiB");
     if (out_pitch < (ptrdiff_t)W * bs || (out_pitch % (bs == 1 ? 8 : 16)) != 0) return fail(JPEGX_E_INVALID, "output pitch too small or misaligned");
     const long long nblocks = (long long)(H / 8) * (W / 8);
-    DevicePool *pool = nullptr;
-    int rc = current_pool(&pool);
-    if (rc) return rc;
-    std::lock_guard<std::mutex> lock(pool->mu);
+    int rc;
     if (!pool->stream && hipStreamCreateWithFlags(&pool->stream, hipStreamNonBlocking) != hipSuccess) return fail(JPEGX_E_HIP, "hipStreamCreate failed");
     hipStream_t st = pool->stream;
     const size_t out_bytes = (size_t)H * bs * out_pitch;
@@ -277,27 +274,33 @@ int jpegx_host_decompress_plane(const uint8_t *h_bytes, size_t nbytes, int H, in
     return decode_status(pool);
 }
 
+int jpegx_host_decompress_plane(const uint8_t *h_bytes, size_t nbytes, int H, int W, int bs, int mode, double param,
+                                uint8_t *h_out, ptrdiff_t out_pitch)
+{
+    DevicePool *pool = nullptr;
+    int rc = current_pool(&pool);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lock(pool->mu);
+    return decompress_plane_locked(pool, h_bytes, nbytes, H, W, bs, mode, param, h_out, out_pitch);
+}
+
 // The same, handing back what the reference's decompress_band returns: a [rows][cols] int64 array (the band
 // cropped to its configured size).  The uint8 samples come down into pinned staging memory and are widened
 // by a few host threads -- NumPy's astype(int) on a 4096 x 4096 band costs more than the device pipeline.
 int jpegx_host_decompress_plane_i64(const uint8_t *h_bytes, size_t nbytes, int H, int W, int bs, int mode, double param,
                                     int64_t *h_out, int rows, int cols)
 {
-    if (!h_out || rows <= 0 || cols <= 0 || rows > H * bs || cols > W * bs) return fail(JPEGX_E_INVALID, "bad output shape");
+    if (!h_out || rows <= 0 || cols <= 0 || H <= 0 || W <= 0 || bs <= 0 || rows > (long long)H * bs || cols > (long long)W * bs)
+        return fail(JPEGX_E_INVALID, "bad output shape");
     const ptrdiff_t pitch = ((ptrdiff_t)W * bs + 15) / 16 * 16;
     const size_t stage_bytes = (size_t)H * bs * pitch;
     DevicePool *pool = nullptr;
     int rc = current_pool(&pool);
     if (rc) return rc;
-    uint8_t *stage = nullptr;
-    {
-        std::lock_guard<std::mutex> lock(pool->mu);
-        if ((rc = pool->h_out.ensure(stage_bytes))) return rc;
-        stage = static_cast<uint8_t *>(pool->h_out.p);
-    }
-    // (the staging span is only ever touched under the pool mutex or, as below, by the thread that just filled it:
-    // one host job per device at a time is the pool's contract)
-    if ((rc = jpegx_host_decompress_plane(h_bytes, nbytes, H, W, bs, mode, param, stage, pitch))) return rc;
+    std::lock_guard<std::mutex> lock(pool->mu);          // held to the end: the staging span belongs to this job
+    if ((rc = pool->h_out.ensure(stage_bytes))) return rc;
+    uint8_t *stage = static_cast<uint8_t *>(pool->h_out.p);
+    if ((rc = decompress_plane_locked(pool, h_bytes, nbytes, H, W, bs, mode, param, stage, pitch))) return rc;
     const unsigned hw = std::thread::hardware_concurrency();
     const int nthreads = ((size_t)rows * cols < (1u << 20)) ? 1 : (hw >= 8 ? 8 : (hw ? (int)hw : 1));
     auto work = [&](int y0, int y1) {

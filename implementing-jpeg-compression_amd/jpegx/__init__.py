@@ -23,6 +23,9 @@ Q_NONE, Q_DISCARD, Q_DIVIDE, Q_QTABLE = 0, 1, 2, 3
 MODE_BY_NAME = {"none": Q_NONE, "discard": Q_DISCARD, "divide": Q_DIVIDE, "qtable": Q_QTABLE}
 F_PIXEL_INPUT = 1
 F_CLAMP_U8 = 2
+F_TUNE_F64_LANE_PER_BLOCK = 0x4
+F_TUNE_F64_KERNEL = 0x4000
+F_TUNE_NO_F64_KERNEL = 0x8000
 F_TUNE_NO_NT = 0x100
 F_TUNE_NO_STRIP = 0x200
 F_TUNE_SKIP_EXACT = 0x400
@@ -352,13 +355,13 @@ def mean_pool_f64(plane, block_size):
         dout.free()
 
 
-def forward_fused_f64(plane, mode="qtable", param=0.0):
+def forward_fused_f64(plane, mode="qtable", param=0.0, flags_extra=0):
     """float64 plane (H, W) -> int16 (H/8, W/8, 64): steps 4+5+6 entirely in float64 in the reference's
     operation order (for samples that are not exact in fp32)."""
     a = _plane(plane, np.float64)
     h, w = a.shape
     out = np.empty((h // 8, w // 8, 64), dtype=np.int16)
-    check(lib().jpegx_host_forward_fused_f64(a.ctypes.data, h, w, mode_of(mode), float(param), 0, out.ctypes.data),
+    check(lib().jpegx_host_forward_fused_f64(a.ctypes.data, h, w, mode_of(mode), float(param), int(flags_extra), out.ctypes.data),
           "jpegx_host_forward_fused_f64")
     return out
 

@@ -59,8 +59,9 @@ typedef enum jpegx_quant_mode {
 #define JPEGX_F_TUNE_SKIP_EXACT 0x400u /* TIMING ONLY: skip the float64 exact tier (output no longer bit-exact) */
 #define JPEGX_F_TUNE_WAVE_PER_BLOCK 0x800u /* forward: one-wavefront-per-block kernel (lane = coefficient,   \
                                               ds_bpermute 1-D passes) instead of lane-per-block; same output */
-#define JPEGX_F_TUNE_F64_KERNEL 0x4000u    /* forward: force the all-float64 lane-per-block kernel           */
+#define JPEGX_F_TUNE_F64_KERNEL 0x4000u    /* forward: force the all-float64 kernel                          */
 #define JPEGX_F_TUNE_NO_F64_KERNEL 0x8000u /* forward: never pick it (fp32 tier + exact tier always)          */
+#define JPEGX_F_TUNE_F64_LANE_PER_BLOCK 0x4u /* forward: the all-float64 kernel in its lane-per-block form (default: 8 lanes per block) */
 #define JPEGX_F_TUNE_POOL_ROWS_LO 0x1000u /* pooled forward: fewer input rows per LDS phase (experiment) */
 #define JPEGX_F_TUNE_POOL_ROWS_HI 0x2000u /* pooled forward: more input rows per LDS phase (experiment)  */
 #define JPEGX_F_TUNE_XCD_CONTIG 0x10000u    /* XCD-private block order: the XCDs take turns in runs of 128 strips, \

@@ -168,7 +168,7 @@ def test_bad_arguments_raise(gpu):
         gpu.forward_fused(np.zeros((8, 8), np.float32), "bogus")
 
 
-@pytest.mark.parametrize("flags", [0x100, 0x200, 0x300, 0x800, 0x900, 0x4000, 0x8000])
+@pytest.mark.parametrize("flags", [0x100, 0x200, 0x300, 0x800, 0x900, 0x4000, 0x4004, 0x4100, 0x8000])
 @pytest.mark.parametrize("kind", ["noise", "smooth"])
 def test_forward_tuning_variants_are_bit_identical(gpu, kind, flags):
     """Cache-policy and LDS-strip variants of the fused forward kernel give the same integers."""
@@ -181,6 +181,45 @@ def test_forward_tuning_variants_are_bit_identical(gpu, kind, flags):
     ties = np.tile(np.load(__import__("os").path.join(__import__("conftest").GOLDEN, "case_ties128.npz"))["pre"], (1, 4))
     assert np.array_equal(gpu.forward_fused(ties.astype(np.float32), "qtable", flags_extra=flags),
                           oracle.forward_f32(ties.astype(np.float32), "qtable"))
+
+
+@pytest.mark.parametrize("shape", [(8, 8), (8, 24), (16, 72), (64, 520), (24, 4104), (1032, 1000)])
+def test_float64_kernel_eight_lanes_per_block(gpu, shape):
+    """k_forward_fused_f64x8 (what fine quantisers get: 'none', small divisors, wide 'discard' windows), forced for
+    every quantiser: block counts that are not multiples of 8 or 16, pitch > W, signed and fractional samples --
+    equal to the oracle and to the lane-per-block float64 kernel it replaces."""
+    h, w = shape
+    rng = np.random.default_rng(h * 10007 + w)
+    planes = [gpu.synth.generate_plane("noise", h, w, seed=5), rng.normal(0, 500, (h, w)).astype(np.float32),
+              (rng.integers(0, 4096, (h, w)) / 16.0).astype(np.float32)]
+    for a in planes:
+        for mode, param in (("none", 0.0), ("qtable", 0.0), ("divide", 1.5), ("divide", -0.75), ("discard", 5.0), ("discard", 0.0),
+                            ("divide", 2.0), ("divide", -4.0), ("divide", 8.0), ("divide", 2.0 ** 60)):
+            want = oracle.forward_f32(a, mode, param)
+            got = gpu.forward_fused(a, mode, param, flags_extra=gpu.F_TUNE_F64_KERNEL)
+            assert np.array_equal(got, want), (shape, mode, param)
+            assert np.array_equal(gpu.forward_fused(a, mode, param, flags_extra=gpu.F_TUNE_F64_KERNEL | gpu.F_TUNE_F64_LANE_PER_BLOCK), want)
+    # amplitudes beyond int16 saturate (the reference keeps float64 there and fails later, in its entropy stage)
+    a = planes[0]
+    for d in (2.0 ** -40, 0.01):
+        sat = gpu.forward_fused(a, "divide", d, flags_extra=gpu.F_TUNE_F64_KERNEL)
+        assert np.array_equal(sat, gpu.forward_fused(a, "divide", d, flags_extra=gpu.F_TUNE_F64_KERNEL | gpu.F_TUNE_F64_LANE_PER_BLOCK))
+        exact = oracle.zigzag_plane(np.rint(oracle.dct_plane(a.astype(np.float64)) / d))
+        assert np.array_equal(sat, np.clip(exact, -32768, 32767).astype(np.int16))
+    # the same kernel on float64 planes (means of block_size 3: multiples of 1/9 are not exact in fp32)
+    thirds = oracle.mean_pool(rng.integers(0, 256, (3 * h, 3 * w)).astype(np.float64), 3)
+    for mode, param in (("qtable", 0.0), ("none", 0.0), ("divide", 2.5), ("discard", 3.0)):
+        want = oracle.zigzag_plane(oracle.quant_plane(oracle.dct_plane(thirds), mode, param)).astype(np.int16)
+        assert np.array_equal(gpu.forward_fused_f64(thirds, mode, param), want), (shape, mode)
+        assert np.array_equal(gpu.forward_fused_f64(thirds, mode, param, flags_extra=gpu.F_TUNE_F64_LANE_PER_BLOCK), want), (shape, mode)
+    # a padded device plane: pitch > W, the padding holds garbage that must not be read into the result
+    pitch = w + 24
+    wide = rng.integers(0, 256, (h, pitch)).astype(np.float32)
+    din, dout = gpu.DeviceBuffer(wide.nbytes), gpu.DeviceBuffer((h // 8) * (w // 8) * 128)
+    din.upload(wide)
+    gpu.forward_fused_device(din.ptr, h, w, dout.ptr, "none", 0.0, gpu.F_PIXEL_INPUT | gpu.F_TUNE_F64_KERNEL, pitch=pitch)
+    gpu.check(gpu.lib().jpegx_device_synchronize())
+    assert np.array_equal(dout.download((h // 8, w // 8, 64), np.int16), oracle.forward_f32(wide[:, :w], "none"))
 
 
 @pytest.mark.parametrize("shape", [(8, 8), (64, 520), (24, 4104), (1032, 1000)])
