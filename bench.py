@@ -134,19 +134,29 @@ def cpu_baseline(size, kind, sample_planes=3):
 # --------------------------------------------------------------------------------------------------
 # the other single-GPU configs of BASELINE.json, timed in the same run (N = 1 only)
 # --------------------------------------------------------------------------------------------------
-def _timed_launches(jpegx, fn, iters, warm=5):
-    """Average duration of `fn` (enqueue-only, default stream) over `iters` back-to-back calls, HIP events."""
+def _timed_launches(jpegx, fn, iters, warm_ms=30.0, min_ms=20.0):
+    """Average duration of `fn` (enqueue-only, default stream) over back-to-back calls, HIP events.  The legs
+    that use this follow host-side verification during which the GPU idles and clocks down, and a launch here is
+    only 0.15-0.5 ms: warm up for `warm_ms` of device time (not a fixed handful of launches), then time at
+    least `iters` calls and at least `min_ms`."""
     L = jpegx.lib()
-    for _ in range(warm):
-        fn()
     e0, e1 = jpegx.Event(), jpegx.Event()
+
+    def batch(n):
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_ms(e1)
     jpegx.check(L.jpegx_device_synchronize(), "sync")
-    e0.record()
-    for _ in range(iters):
-        fn()
-    e1.record()
-    e1.synchronize()
-    return e0.elapsed_ms(e1) / iters
+    per = max(batch(5) / 5, 1e-3)
+    spent = per * 5
+    while spent < warm_ms:
+        n = int(min(400, max(5, (warm_ms - spent) / per + 1)))
+        spent += batch(n)
+    n = int(max(iters, min(2000, min_ms / per + 1)))
+    return batch(n) / n
 
 
 def config3(jpegx, kind, iters, verify):
