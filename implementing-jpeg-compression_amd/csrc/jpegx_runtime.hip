@@ -53,6 +53,33 @@ int jpegx_get_device(int *device)
     return JPEGX_OK;
 }
 
+namespace {
+// current device of the calling thread switched to `device` for the lifetime of the object
+struct DeviceScope {
+    int prev = -1, rc = JPEGX_OK;
+    explicit DeviceScope(int device)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) { prev = -1; rc = fail(JPEGX_E_HIP, "hipGetDevice failed"); return; }
+        if (device != prev && hipSetDevice(device) != hipSuccess) { prev = -1; rc = fail(JPEGX_E_INVALID, "no such device"); }
+    }
+    ~DeviceScope() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+}  // namespace
+
+int jpegx_forward_fused_on(int device, const float *d_in, int H, int W, ptrdiff_t pitch, int mode, double param,
+                           unsigned flags, int16_t *d_out, jpegx_stream_t stream)
+{
+    DeviceScope scope(device);
+    return scope.rc ? scope.rc : jpegx_forward_fused(d_in, H, W, pitch, mode, param, flags, d_out, stream);
+}
+
+int jpegx_inverse_fused_on(int device, const int16_t *d_in, int H, int W, int mode, double param, unsigned flags,
+                           void *d_out, ptrdiff_t out_pitch, int out_type, jpegx_stream_t stream)
+{
+    DeviceScope scope(device);
+    return scope.rc ? scope.rc : jpegx_inverse_fused(d_in, H, W, mode, param, flags, d_out, out_pitch, out_type, stream);
+}
+
 int jpegx_device_name(int device, char *buf, size_t buflen)
 {
     if (!buf || buflen == 0) return fail(JPEGX_E_INVALID, "null name buffer");

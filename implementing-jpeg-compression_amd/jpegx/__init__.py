@@ -83,12 +83,14 @@ SIGNATURES = {
     "jpegx_event_elapsed_ms": [_vp, _vp, _c.POINTER(_c.c_float)],
     "jpegx_generate_plane": [_vp, _int, _int, _pd, _int, _u32, _u32, _int, _vp],
     "jpegx_forward_fused": [_vp, _int, _int, _pd, _int, _dbl, _uint, _vp, _vp],
+    "jpegx_forward_fused_on": [_int, _vp, _int, _int, _pd, _int, _dbl, _uint, _vp, _vp],
     "jpegx_forward_fused_pooled": [_vp, _int, _int, _pd, _int, _int, _dbl, _uint, _vp, _vp],
     "jpegx_forward_fused_u8": [_vp, _int, _int, _pd, _int, _int, _dbl, _uint, _vp, _vp],
     "jpegx_forward_fused_planes": [_vp, _int, _int, _dbl, _uint, _vp],
     "jpegx_forward_fused_f64": [_vp, _int, _int, _pd, _int, _dbl, _uint, _vp, _vp],
     "jpegx_mean_pool_f64": [_vp, _int, _int, _int, _pd, _int, _vp, _pd, _vp],
     "jpegx_inverse_fused": [_vp, _int, _int, _int, _dbl, _uint, _vp, _pd, _int, _vp],
+    "jpegx_inverse_fused_on": [_int, _vp, _int, _int, _int, _dbl, _uint, _vp, _pd, _int, _vp],
     "jpegx_inverse_fused_u8_inflated": [_vp, _int, _int, _int, _dbl, _uint, _int, _vp, _pd, _vp],
     "jpegx_dct8x8_f32": [_vp, _int, _int, _pd, _vp, _pd, _vp],
     "jpegx_idct8x8_f32": [_vp, _int, _int, _pd, _vp, _pd, _vp],

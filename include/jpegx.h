@@ -175,6 +175,15 @@ int jpegx_forward_fused_u8(const uint8_t *d_in, int H, int W, ptrdiff_t pitch, i
 int jpegx_inverse_fused(const int16_t *d_in, int H, int W, int mode, double param, unsigned flags,
                         void *d_out, ptrdiff_t out_pitch, int out_type, jpegx_stream_t stream);
 
+/* The two hot entries with an explicit device index ("every entry takes a device index and
+ * an optional stream handle"): the pointers and the stream must belong to `device`; the calling thread's
+ * current device is left as it was.  Every other entry works on the thread's current device
+ * (jpegx_set_device), which is what a one-process-per-GPU job sets once at start.                       */
+int jpegx_forward_fused_on(int device, const float *d_in, int H, int W, ptrdiff_t pitch, int mode, double param,
+                           unsigned flags, int16_t *d_out, jpegx_stream_t stream);
+int jpegx_inverse_fused_on(int device, const int16_t *d_in, int H, int W, int mode, double param, unsigned flags,
+                           void *d_out, ptrdiff_t out_pitch, int out_type, jpegx_stream_t stream);
+
 /* Inverse straight to displayable samples: uint8 with the clamp of pipeline/normalization.py:10-14
  * AND SubSampling.invert (pipeline/subsampling.py:13-14 -> util.inflate, util.py:6-14) fused:
  * every sample is replicated bs x bs times (bs in {1,2,4}); d_out is [H*bs][out_pitch >= W*bs]. */

@@ -1,5 +1,5 @@
 // microbench/membench_xcd.hip -- streaming ceilings with and without the XCD-private workgroup order, at the
-// bench's working-set sizes.  2:1 nontemporal read:write mix (the forward kernel's traffic), read-only, write-only.
+// bench's working-set sizes.  2:1 nontemporal read:write mix (the forward kernel's traffic), read-only, write-only, 1:2 mix (the inverse's).
 // Build: hipcc --offload-arch=gfx950 -O3 -o microbench/membench_xcd microbench/membench_xcd.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -23,6 +23,16 @@ __global__ __launch_bounds__(256) void k_mix(const f32x4 *__restrict__ in, f32x4
         const f32x4 a = __builtin_nontemporal_load(&in[2 * (i - threadIdx.x) + threadIdx.x]);
         const f32x4 b = __builtin_nontemporal_load(&in[2 * (i - threadIdx.x) + 256 + threadIdx.x]);
         __builtin_nontemporal_store(a + b, &out[i]);
+    }
+}
+// the inverse kernel's traffic: one 16-byte read, two 16-byte writes per thread (1:2)
+__global__ __launch_bounds__(256) void k_mix12(const f32x4 *__restrict__ in, f32x4 *__restrict__ out, size_t n4in, int logr)
+{
+    const size_t i = wg_index(logr) * 256 + threadIdx.x;
+    if (i < n4in) {
+        const f32x4 a = __builtin_nontemporal_load(&in[i]);
+        __builtin_nontemporal_store(a, &out[2 * (i - threadIdx.x) + threadIdx.x]);
+        __builtin_nontemporal_store(a + a, &out[2 * (i - threadIdx.x) + 256 + threadIdx.x]);
     }
 }
 __global__ __launch_bounds__(256) void k_rd(const f32x4 *__restrict__ in, size_t n4, float *sink, int logr)
@@ -60,7 +70,10 @@ int main()
             ms = time_ms([&] { hipLaunchKernelGGL(k_rd, dim3(gr), dim3(256), 0, 0, (const f32x4 *)in, n4in, sink, logr); }, iters);
             printf("   read-only %.1f GB/s", 1.0 * nin * 4 / ms / 1e6);
             ms = time_ms([&] { hipLaunchKernelGGL(k_wr, dim3(gm), dim3(256), 0, 0, (f32x4 *)out, n4out, logr); }, iters);
-            printf("   write-only %.1f GB/s\n", 0.5 * nin * 4 / ms / 1e6);
+            printf("   write-only %.1f GB/s", 0.5 * nin * 4 / ms / 1e6);
+            // 1:2: the half-size buffer is read, the full-size buffer written (the fused inverse: int16 in, fp32 out)
+            ms = time_ms([&] { hipLaunchKernelGGL(k_mix12, dim3(gm), dim3(256), 0, 0, (const f32x4 *)out, (f32x4 *)in, n4out, logr); }, iters);
+            printf("   mix 1:2 nt %.1f GB/s\n", 1.5 * nin * 4 / ms / 1e6);
         }
         CK(hipFree(in)); CK(hipFree(out)); CK(hipFree(sink));
     }

@@ -410,6 +410,29 @@ def test_random_shapes_modes_and_values_against_oracle(gpu):
         assert np.array_equal(back.astype(np.int64), oracle.inverse_i16(want, mode, param)), (trial, mode, param)
 
 
+def test_hot_entries_with_an_explicit_device_index(gpu):
+    """jpegx_forward_fused_on / jpegx_inverse_fused_on: same results as on the current device, the thread's current
+    device is unchanged afterwards, a device that does not exist is an error and not a fault."""
+    L = gpu.lib()
+    a = gpu.synth.generate_plane("noise", 64, 128, seed=2)
+    want = oracle.forward_f32(a, "qtable")
+    din, dzz, dout = gpu.DeviceBuffer(a.nbytes), gpu.DeviceBuffer(want.nbytes), gpu.DeviceBuffer(a.nbytes)
+    din.upload(a)
+    cur = ctypes.c_int(-1)
+    gpu.check(L.jpegx_get_device(ctypes.byref(cur)))
+    gpu.check(L.jpegx_forward_fused_on(cur.value, din.ptr, 64, 128, 128, gpu.mode_of("qtable"), 0.0, gpu.F_PIXEL_INPUT, dzz.ptr, None))
+    gpu.check(L.jpegx_inverse_fused_on(cur.value, dzz.ptr, 64, 128, gpu.mode_of("qtable"), 0.0, 0, dout.ptr, 128, gpu.OUT_F32, None))
+    gpu.check(L.jpegx_device_synchronize())
+    assert np.array_equal(dzz.download(want.shape, np.int16), want)
+    assert np.array_equal(dout.download(a.shape, np.float32).astype(np.int32), oracle.inverse_i16(want, "qtable"))
+    after = ctypes.c_int(-1)
+    gpu.check(L.jpegx_get_device(ctypes.byref(after)))
+    assert after.value == cur.value
+    assert L.jpegx_forward_fused_on(4096, din.ptr, 64, 128, 128, gpu.mode_of("qtable"), 0.0, 0, dzz.ptr, None) != 0
+    gpu.check(L.jpegx_get_device(ctypes.byref(after)))
+    assert after.value == cur.value
+
+
 def test_native_rccl_gather_single_rank(gpu):
     """jpegx_comm_* on a 1-rank communicator: the gather is a send+recv to self through RCCL.  (More
     ranks need more GPUs; the driver's multi-GPU run and tests/test_multigpu_cpu.py cover the sharding.)"""
