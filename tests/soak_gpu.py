@@ -128,7 +128,8 @@ def compare(tally, leg, got, want, detail):
 
 
 FWD_VARIANTS = [("auto", 0), ("strip", gpu.F_TUNE_NO_COLUMN_UNITS), ("cols", gpu.F_TUNE_COLUMN_UNITS),
-                ("xcd", gpu.F_TUNE_XCD_CONTIG), ("wpb", gpu.F_TUNE_WAVE_PER_BLOCK), ("nostrip", gpu.F_TUNE_NO_STRIP)]
+                ("xcd", gpu.F_TUNE_XCD_CONTIG), ("wpb", gpu.F_TUNE_WAVE_PER_BLOCK), ("nostrip", gpu.F_TUNE_NO_STRIP),
+                ("float64 eight lanes", gpu.F_TUNE_F64_KERNEL), ("float64 lane per block", gpu.F_TUNE_F64_KERNEL | gpu.F_TUNE_F64_LANE_PER_BLOCK)]
 
 
 def one_round(rng, tally, size):
@@ -191,6 +192,24 @@ def one_round(rng, tally, size):
                         gpu.inverse_fused(zz, mode, param, out="i16", clamp=clamp), wanti, tag)
         else:
             compare(tally, "inverse fp32 (%s)" % leg, gpu.inverse_fused(zz, mode, param, out="f32"), ref, tag)
+
+    # the whole band job through the native host pipeline (what compress_band / decompress_band call)
+    if w % 16 == 0 and rng.random() < 0.5:
+        k = [1, 2, 4, 3][int(rng.integers(0, 4))]
+        hk = (h // (8 * k)) * 8 * k
+        wk = (w // (16 * k)) * 16 * k if k != 3 else (w // 24) * 24
+        if hk and wk and (mode != "none") and gpu.u8_path_ok(wk // k, k if k != 3 else 1, wk, mode, param):
+            band = np.ascontiguousarray(u8[:hk, :wk])
+            pooledk = oracle.mean_pool(band, k)
+            zk = oracle_forward_f64(pooledk, mode, param).astype(np.int16)
+            if np.abs(zk).max() < 16384:
+                blob = gpu.compress_plane(band, k, mode, param)
+                ref_blob = oracle.rle_bytestream(zk)
+                tally.add("compress_plane block_size %d (bytes)" % k, len(ref_blob), 0 if blob == ref_blob else max(1, abs(len(blob) - len(ref_blob))), tag)
+                if k != 3:
+                    refp = np.clip(oracle_inverse(zk, mode, param), 0, 255).astype(np.uint8)
+                    compare(tally, "decompress_plane block_size %d" % k, gpu.decompress_plane(ref_blob, hk // k, wk // k, k, mode, param),
+                            np.repeat(np.repeat(refp, k, 0), k, 1), tag)
 
     # entropy stage both ways on the device
     if np.abs(want).max() < 16384 and rng.random() < 0.5:
