@@ -63,10 +63,11 @@ def parse_args():
     ap.add_argument("--spinup-ms", type=float, default=60.0,
                     help="untimed launches before the W warm-up steps so that the GPU leaves its idle clocks")
     ap.add_argument("--gather-chunk", type=int, default=4, help="planes per send/recv round of the overlapped gather")
-    ap.add_argument("--gather-timeout", type=float, default=240.0, help="seconds the gather legs may take before rank 0 reports without them")
+    ap.add_argument("--gather-timeout", type=float, default=150.0, help="seconds the gather legs may take before rank 0 reports without them")
     ap.add_argument("--share-device", action="store_true",
                     help="rehearsal on ONE GPU: every rank uses GPU 0 and a 1-rank RCCL communicator "
                          "(loop-back send/recv); exercises launcher, control plane, events and streams")
+    ap.add_argument("--dry-run-stall", type=float, default=0.0, help="with --dry-run: seconds every rank stalls inside the watchdog-guarded region")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU work at all: launcher + control plane + shard plan only (CPU tests)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -134,6 +135,19 @@ def cpu_baseline(size, kind, sample_planes=3):
 # --------------------------------------------------------------------------------------------------
 # the other single-GPU configs of BASELINE.json, timed in the same run (N = 1 only)
 # --------------------------------------------------------------------------------------------------
+def guarded(seconds, on_expire, fn):
+    """Run ``fn()`` with a watchdog: ``on_expire`` is called from a timer thread when it has not returned after
+    ``seconds`` (it is expected to report what is already known and leave the process)."""
+    import threading
+    dog = threading.Timer(seconds, on_expire)
+    dog.daemon = True
+    dog.start()
+    try:
+        return fn()
+    finally:
+        dog.cancel()
+
+
 def _timed_launches(jpegx, fn, iters, warm_ms=30.0, min_ms=20.0):
     """Average duration of `fn` (enqueue-only, default stream) over back-to-back calls, HIP events.  The legs
     that use this follow host-side verification during which the GPU idles and clocks down, and a launch here is
@@ -284,9 +298,19 @@ def run(args, rank, local_rank, world, ctl, emit):
         ok = ctl.all_ok(ident == bytes(range(128)) and seen[rank][0] == rank)
         t = ctl.allreduce_max(float(rank))
         ctl.barrier()
+        line = {"dry_run": True, "n_gpus": world, "shards": [s[1:3] for s in seen], "all_ok": ok,
+                "max_rank": t, "launcher": os.environ.get("JPEGX_LAUNCHER", "external")}
+        if args.dry_run_stall > 0:
+            # rehearsal of the watchdog that guards the gather legs of a real run: the "exchange" below never
+            # comes back in time, rank 0 must still print its line and every rank must leave with status 0
+            def give_up():
+                line["gather"] = {"error": "gather legs did not finish within %.0f s; compute-phase result kept" % args.gather_timeout}
+                if rank == 0:
+                    emit(line)
+                os._exit(0)
+            guarded(args.gather_timeout, give_up, lambda: time.sleep(args.dry_run_stall))
         if rank == 0:
-            emit({"dry_run": True, "n_gpus": world, "shards": [s[1:3] for s in seen], "all_ok": ok,
-                  "max_rank": t, "launcher": os.environ.get("JPEGX_LAUNCHER", "external")})
+            emit(line)
         return
 
     import jpegx
@@ -417,22 +441,22 @@ def run(args, rank, local_rank, world, ctl, emit):
     # (the only part that waits on other GPUs) not come back within --gather-timeout seconds, rank 0 still
     # prints the line, with the timeout recorded under "gather", and every rank leaves.
     if gathering:
-        import threading
-
         def give_up():
             result["gather"] = {"error": "gather legs did not finish within %.0f s; compute-phase result kept" % args.gather_timeout}
             if rank == 0:
                 emit(result)
-            os._exit(0 if rank == 0 else 3)
-        dog = threading.Timer(args.gather_timeout, give_up)
-        dog.daemon = True
-        dog.start()
-        try:
-            gather, end_to_end = gather_legs(args, jpegx, multigpu, ctl, rank, world, spans, in_ptr, out_ptr, root_ptr,
-                                             plane_out, total_blocks_per_step, loopback)
-        except multigpu.ControlPlaneError as exc:      # a rank dropped out: keep the measured compute phase
-            gather, end_to_end = {"error": "control plane: %s" % str(exc)[:300]}, None
-        dog.cancel()
+            # every rank leaves with status 0: the compute-phase measurement is complete and valid, the failed
+            # exchange is recorded in the line itself -- a non-zero status would make the launcher tear the job
+            # down (possibly before rank 0 has printed) and report the whole run as failed
+            os._exit(0)
+
+        def legs():
+            try:
+                return gather_legs(args, jpegx, multigpu, ctl, rank, world, spans, in_ptr, out_ptr, root_ptr,
+                                   plane_out, total_blocks_per_step, loopback)
+            except multigpu.ControlPlaneError as exc:      # a rank dropped out: keep the measured compute phase
+                return {"error": "control plane: %s" % str(exc)[:300]}, None
+        gather, end_to_end = guarded(args.gather_timeout, give_up, legs)
         if gather is not None:
             result["gather"] = gather
         if end_to_end is not None:

@@ -7,6 +7,7 @@ import json
 import os
 import socket
 import subprocess
+import time
 import sys
 
 import numpy as np
@@ -180,6 +181,28 @@ def test_bench_runs_as_ranks_of_torch_distributed_run(tmp_path):
     line = _bench_line(subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600))
     assert line["dry_run"] and line["n_gpus"] == 2 and line["shards"] == [[0, 512], [512, 1024]]
     assert line["launcher"] == "external"
+
+
+@pytest.mark.parametrize("launcher", ["own", "torch"])
+def test_watchdog_of_the_gather_legs_keeps_the_result_line(tmp_path, launcher):
+    """An exchange that never comes back (rehearsed with --dry-run-stall): rank 0 still prints its line, with the
+    timeout recorded under "gather", every rank leaves with status 0 and the job as a whole reports success --
+    under the own launcher and as ranks of torch.distributed.run."""
+    env = dict(os.environ, JPEGX_CTL_DIR=str(tmp_path), OMP_NUM_THREADS="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    tail = [os.path.join(REPO, "bench.py"), "--gpus", "2", "--dry-run", "--dry-run-stall", "120", "--gather-timeout", "1"]
+    if launcher == "own":
+        cmd = [sys.executable] + tail
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port())] + tail
+    t0 = time.time()
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    line = _bench_line(res)
+    assert res.returncode == 0
+    assert line["dry_run"] and line["n_gpus"] == 2 and "did not finish within 1 s" in line["gather"]["error"]
+    assert time.time() - t0 < 100          # nobody sat out the 120 s stall
 
 
 GLOO_WORKER = r'''
