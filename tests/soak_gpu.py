@@ -165,7 +165,12 @@ def one_round(rng, tally, size):
     # signed / fractional samples through the generic variant
     if rng.random() < 0.3:
         g = (rng.normal(0, float(rng.choice([3.0, 60.0, 400.0])), (h, w))).astype(np.float32)
-        compare(tally, "forward fractional fp32", gpu.forward_fused(g, mode, param), oracle_forward(g, mode, param), tag)
+        try:
+            wantg = oracle_forward(g, mode, param)
+        except ValueError:                  # amplitudes beyond int16: the oracle refuses (the kernels saturate; pytest covers that)
+            wantg = None
+        if wantg is not None:
+            compare(tally, "forward fractional fp32", gpu.forward_fused(g, mode, param), wantg, tag)
 
     # inverse: the stream just made, and the same stream with random coefficient noise on top
     for leg, zz in (("stream", want), ("perturbed", None)):
