@@ -35,9 +35,9 @@ __global__ __launch_bounds__(256) void k_rate(double *out, int iters, double see
 }
 
 template <int OP>
-void run(const char *name, double *d)
+void run(const char *name, double *d, int waves_per_simd = 8)
 {
-    const int iters = 4096, grid = 256 * 8;            // 8 workgroups of 4 waves per CU: 8 waves per SIMD
+    const int iters = 4096, grid = 256 * waves_per_simd;            // workgroups of 4 waves, one wave per SIMD each
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     hipLaunchKernelGGL((k_rate<OP>), dim3(grid), dim3(256), 0, 0, d, 16, 1.0);
@@ -50,7 +50,7 @@ void run(const char *name, double *d)
     hipEventElapsedTime(&ms, e0, e1);
     const double wave_instr = (double)grid * 4 * iters * 32;           // wave-level instructions issued
     const double per_simd_per_s = wave_instr / (ms * 1e-3) / (256 * 4);
-    printf("%-16s %8.3f ms  %7.2f G wave-instr/s per SIMD  = %5.2f cycles per instruction at 2.4 GHz\n", name, ms,
+    printf("%-16s %d waves/SIMD %8.3f ms  %7.2f G wave-instr/s per SIMD  = %5.2f cycles per instruction at 2.4 GHz\n", name, waves_per_simd, ms,
            per_simd_per_s * 1e-9, 2.4e9 / per_simd_per_s);
 }
 
@@ -65,5 +65,7 @@ int main()
     run<3>("v_cvt_f64_f32", d);
     run<4>("v_rndne_f64", d);
     run<6>("v_cvt_i32_f64", d);
+    for (int w : {1, 2, 3, 4, 6}) run<0>("v_fma_f64", d, w);
+    for (int w : {1, 2, 4}) run<5>("v_fma_f32", d, w);
     return 0;
 }
