@@ -291,6 +291,7 @@ int fail(int code, const char *msg)
     do {                                                                                   \
         hipError_t e_ = (expr);                                                            \
         if (e_ != hipSuccess) {                                                            \
+            (void)hipGetLastError(); /* reported here: must not linger as the thread's last error */ \
             char buf_[400];                                                                \
             snprintf(buf_, sizeof(buf_), "%s failed: %s", #expr, hipGetErrorString(e_));   \
             return fail(JPEGX_E_HIP, buf_);                                                \

@@ -13,10 +13,12 @@
 //     rounding boundary raises a flag; the wave then recomputes each flagged block
 //     cooperatively in float64 in the reference's operation order (lane = one coefficient,
 //     two LDS exchanges) and patches the tile.  See jpegx_math.h / DESIGN.md.
-////
-// This file: the fused forward kernels (fp32 strip kernel = default, per-lane / LDS-staged pooled
-// variants, uint8 input, the one-wavefront-per-block comparison variant) and their C entry points.
-// Built with: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (explicit fma only).
+//
+// This file: the fused forward kernels (fp32 strip kernel = default, its column-wise-tier form for finer
+// quantisers, per-lane / LDS-staged pooled variants, several planes in one grid, uint8 input, the
+// all-float64 kernel with eight lanes per block for the finest quantisers and float64 planes, the
+// one-wavefront-per-block and lane-per-block-float64 comparison variants) and their C entry points.
+// Built with: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize (explicit fma only).
 #include "jpegx_internal.h"
 #include <string.h>
 

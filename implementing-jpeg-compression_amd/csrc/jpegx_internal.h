@@ -29,6 +29,7 @@ int fail(int code, const char *fmt, const char *detail = "")
     do {                                                                                 \
         hipError_t e_ = (expr);                                                          \
         if (e_ != hipSuccess) {                                                          \
+            (void)hipGetLastError(); /* reported here: must not linger as the thread's last error */ \
             snprintf(g_err, sizeof(g_err), "%s failed: %s", #expr, hipGetErrorString(e_)); \
             return JPEGX_E_HIP;                                                          \
         }                                                                                \

@@ -60,7 +60,11 @@ struct DeviceScope {
     explicit DeviceScope(int device)
     {
         if (hipGetDevice(&prev) != hipSuccess) { prev = -1; rc = fail(JPEGX_E_HIP, "hipGetDevice failed"); return; }
-        if (device != prev && hipSetDevice(device) != hipSuccess) { prev = -1; rc = fail(JPEGX_E_INVALID, "no such device"); }
+        if (device != prev && hipSetDevice(device) != hipSuccess) {
+            (void)hipGetLastError();          // the refused index must not linger as the thread's "last error"
+            prev = -1;
+            rc = fail(JPEGX_E_INVALID, "no such device");
+        }
     }
     ~DeviceScope() { if (prev >= 0) (void)hipSetDevice(prev); }
 };

@@ -431,6 +431,12 @@ def test_hot_entries_with_an_explicit_device_index(gpu):
     assert L.jpegx_forward_fused_on(4096, din.ptr, 64, 128, 128, gpu.mode_of("qtable"), 0.0, 0, dzz.ptr, None) != 0
     gpu.check(L.jpegx_get_device(ctypes.byref(after)))
     assert after.value == cur.value
+    # a refused HIP call is reported once, by the entry that made it: it must not linger as the thread's "last
+    # error" and fail the next, perfectly good launch (every launch is followed by a hipGetLastError check)
+    assert L.jpegx_set_device(4096) != 0
+    assert np.array_equal(gpu.forward_fused(a, "qtable"), want)
+    gpu.check(L.jpegx_forward_fused(din.ptr, 64, 128, 128, gpu.mode_of("qtable"), 0.0, gpu.F_PIXEL_INPUT, dzz.ptr, None))
+    gpu.check(L.jpegx_device_synchronize())
 
 
 def test_native_rccl_gather_single_rank(gpu):
