@@ -410,6 +410,26 @@ def test_random_shapes_modes_and_values_against_oracle(gpu):
         assert np.array_equal(back.astype(np.int64), oracle.inverse_i16(want, mode, param)), (trial, mode, param)
 
 
+@pytest.mark.parametrize("flags", [0, 0x40000, 0x4000, 0x4004, 0x800, 0x200])
+def test_non_finite_and_huge_samples_stay_inside_their_block(gpu, flags):
+    """NaN, +-Inf and 1e30 in a float plane (the reference would fail on them at its integer conversion): every
+    kernel variant returns, and the blocks that do not contain such a sample are what they are without them."""
+    clean = gpu.synth.generate_plane("noise", 64, 256, seed=12).astype(np.float32)
+    dirty = clean.copy()
+    bad = {3: np.nan, 5: np.inf, 7: -np.inf, 9: 1e30, 11: -1e30, 40: 3e38, 77: np.nan}
+    for blk, val in bad.items():
+        by, bx = divmod(blk, 256 // 8)
+        dirty[by * 8 + (blk % 5), bx * 8 + (blk % 7)] = val
+    keep = np.ones((64 // 8) * (256 // 8), dtype=bool)
+    keep[list(bad)] = False
+    for mode, param in (("qtable", 0.0), ("none", 0.0), ("divide", 3.0)):
+        want = oracle.forward_f32(clean, mode, param).reshape(-1, 64)
+        got = gpu.forward_fused(dirty, mode, param, pixel_input=False, flags_extra=flags).reshape(-1, 64)
+        assert np.array_equal(got[keep], want[keep]), (mode, flags)
+    got64 = gpu.forward_fused_f64(dirty.astype(np.float64), "qtable").reshape(-1, 64)
+    assert np.array_equal(got64[keep], oracle.forward_f32(clean, "qtable").reshape(-1, 64)[keep])
+
+
 def test_hot_entries_with_an_explicit_device_index(gpu):
     """jpegx_forward_fused_on / jpegx_inverse_fused_on: same results as on the current device, the thread's current
     device is unchanged afterwards, a device that does not exist is an error and not a fault."""
