@@ -15,6 +15,10 @@
 //   4. starts      block i starts at the candidate reached from position 0 by following the bits of i;
 //   5. decode      lane per block, values into an LDS tile, coalesced 1 KiB stores into the zigzag stream.
 // Steps 1-4 read the stream twice and touch ~1.4 candidates per block; the result equals the host parser's.
+// One difference on DAMAGED input: the host parser skips the padding bits unread, so a stream whose padding has
+// been tampered with still parses there, while here the block behind it is not found (its start is not behind a
+// 0x00 byte) and the stream is refused; the callers (decompress_band) then take the host parser.  The encoder
+// always writes zero padding (rle_byte_stream.py:55-56).  tests/test_gpu_entropy.py fuzzes both decoders.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 

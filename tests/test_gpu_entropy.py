@@ -138,6 +138,50 @@ def test_device_entropy_decoder_rejects_what_the_host_parser_rejects(gpu):
             gpu.entropy_decode(bad, n)
 
 
+def test_device_and_host_decoders_agree_on_damaged_streams(gpu):
+    """Seeded fuzz of the two decoders (parallel on the device, sequential C++ on the host) on random bytes and on
+    well-formed streams with flipped bits, truncations and inserted bytes: the device never accepts what the host
+    parser rejects, what both accept decodes to the same coefficients, and no input faults or hangs the device.
+    The device is stricter in exactly one respect: it finds block starts behind 0x00 bytes, so a block whose
+    zero padding after the end marker has been damaged is refused there (decompress_band then takes the host
+    parser, which skips padding bits unread) -- the encoder never writes such padding (rle_byte_stream.py:55-56)."""
+    rng = np.random.default_rng(5)
+    seen = {"equal": 0, "both refuse": 0, "device stricter": 0}
+    for trial in range(240):
+        nb = int(rng.integers(1, 200))
+        kind = trial % 4
+        if kind == 0:
+            blob = rng.integers(0, 256, int(rng.integers(1, 4096)), dtype=np.uint8).tobytes()
+        else:
+            zz = (rng.integers(-300, 300, (nb, 64)) * (rng.random((nb, 64)) < rng.random())).astype(np.int16)
+            dmg = bytearray(oracle.rle_bytestream(zz.reshape(nb, 1, 64)))
+            if kind == 1:
+                for _ in range(int(rng.integers(1, 4))):
+                    dmg[int(rng.integers(0, len(dmg)))] ^= 1 << int(rng.integers(0, 8))
+            elif kind == 2:
+                dmg = dmg[:int(rng.integers(1, len(dmg) + 1))]
+            else:
+                i = int(rng.integers(0, len(dmg)))
+                dmg[i:i] = rng.integers(0, 256, int(rng.integers(1, 9)), dtype=np.uint8).tobytes()
+            blob = bytes(dmg)
+        for n in ((nb, max(1, nb - 1)) if trial % 7 == 0 else (nb,)):
+            try:
+                host = gpu.entropy_decode(blob, n)
+            except gpu.JpegxError:
+                host = None
+            try:
+                dev = gpu.entropy_decode_gpu(blob, n)
+            except gpu.JpegxError:
+                dev = None
+            assert not (dev is not None and host is None), (trial, n)
+            if dev is not None:
+                assert np.array_equal(dev, host), (trial, n)
+                seen["equal"] += 1
+            else:
+                seen["both refuse" if host is None else "device stricter"] += 1
+    assert seen["equal"] >= 10 and seen["both refuse"] >= 100 and seen["device stricter"] <= 5, seen
+
+
 @pytest.mark.parametrize("bs", [1, 2, 4])
 def test_decompress_plane_all_on_device(gpu, bs):
     """bytes -> samples without the coefficients ever visiting the host == host parse + fused inverse."""
