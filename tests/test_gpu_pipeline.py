@@ -145,6 +145,37 @@ def test_decompress_band_fast_path_equals_generic_path(gpu, golden):
     assert np.array_equal(fast, a) and np.array_equal(fast, c["band_qtable"])
 
 
+def test_stream_with_damaged_padding_takes_the_host_parser_and_gives_its_result(gpu, golden):
+    """The device decoder refuses a stream whose zero padding behind an end marker has been tampered with (it finds
+    block starts behind 0x00 bytes); the sequential parser -- like the reference's -- never reads padding bits.
+    decompress_band must then return what the step-by-step walk over the damaged stream returns."""
+    import jpegx
+    from pipeline.base import step_classes
+    c = golden("pooled128")
+    cfg = config_for(c, QuantizationMethod("qtable"))
+    blob = bytearray(compress_band(c["input"].astype(np.int64), cfg))
+    nblocks = (c["input"].shape[0] // cfg.block_size // 8) * (c["input"].shape[1] // cfg.block_size // 8)
+    damaged = None
+    for i in range(1, len(blob) - 1):                      # a 0x00 byte that ends a block early in the stream: set its last bit
+        if blob[i] == 0:
+            trial = bytes(blob[:i]) + b"\x01" + bytes(blob[i + 1:])
+            try:
+                jpegx.entropy_decode(trial, nblocks)
+            except jpegx.JpegxError:
+                continue
+            try:
+                jpegx.entropy_decode_gpu(trial, nblocks)
+            except jpegx.JpegxError:
+                damaged = trial
+                break
+    assert damaged is not None, "no padding bit found to tamper with"
+    a = damaged
+    for cls in reversed(step_classes):
+        a = cls(cfg).invert(a)
+    assert np.array_equal(decompress_band(damaged, cfg), a)
+    assert np.array_equal(pipeline.decompress_band_u8(damaged, cfg), a.astype(np.uint8))
+
+
 def _step_by_step(band, cfg, classes):
     a = band
     for cls in classes:
