@@ -51,6 +51,84 @@ def test_gather_plan_places_every_plane_exactly_once():
             assert plan.round_of(r, plan.rounds)[1] == 0
 
 
+@pytest.mark.parametrize("world, n_planes, chunk", [(1, 3, 2), (2, 7, 4), (3, 7, 2), (4, 10, 1), (8, 1024, 4), (8, 13, 5), (5, 5, 9)])
+def test_driver_step_matches_sends_and_receives_for_every_world(monkeypatch, world, n_planes, chunk):
+    """jpegx.multigpu.transform_and_gather played rank by rank on the CPU with the device calls replaced by recorders:
+    every rank transforms each of its planes exactly once, into its own slot; round by round what a rank sends is
+    what the root has posted a receive for (same byte count, landing at that plane's offset of the root's stream);
+    the root sends nothing and receives nothing from itself; event and wait calls pair up round by round."""
+    import jpegx
+    from jpegx import multigpu
+    plane_in, plane_out, size = 64 * 64 * 4, 64 * 64 * 2, 64
+    plan = multigpu.GatherPlan(n_planes, world, plane_out, chunk)
+
+    class FakeLib:
+        def __init__(self):
+            self.log = []
+
+        def jpegx_event_record(self, ev, stream):
+            self.log.append(("record", ev, stream))
+            return 0
+
+        def jpegx_stream_wait_event(self, stream, ev):
+            self.log.append(("wait", ev, stream))
+            return 0
+
+    class Ev:
+        def __init__(self, k):
+            self.handle = 1000 + k
+
+    class Recorder:
+        def __init__(self, rank):
+            self.rank, self.nranks, self.calls = rank, world, []
+
+        def gather_bytes(self, send_ptr, send_bytes, recv_ptr, recv_bytes, recv_offsets, root=0, stream=None):
+            self.calls.append((send_ptr, send_bytes, recv_ptr, list(recv_bytes), list(recv_offsets), root, stream))
+
+    per_rank = {}
+    for rank in range(world):
+        lo, hi = plan.spans[rank]
+        fake, launches = FakeLib(), []
+        monkeypatch.setattr(jpegx, "lib", lambda fake=fake: fake)
+        monkeypatch.setattr(jpegx, "check", lambda rc, what="": None)
+        monkeypatch.setattr(jpegx, "forward_fused_device",
+                            lambda in_ptr, h, w, out_ptr, mode, param, flags, stream=None, launches=launches: launches.append((in_ptr, h, w, out_ptr, stream)))
+        in_base, root_base = 1 << 40, 1 << 44
+        stream_ptr = (root_base + lo * plane_out) if rank == 0 else (1 << 42)
+        comm = Recorder(rank)
+        multigpu.transform_and_gather(comm, plan, in_base, stream_ptr, root_base if rank == 0 else None, size, "qtable", 0.0, 1,
+                                      "compute", "comm", [Ev(k) for k in range(plan.rounds)], root=0)
+        # every own plane transformed exactly once, from and into its own slot
+        done = []
+        for in_ptr, h, w, out_ptr, stream in launches:
+            assert stream == "compute" and w == size and h % size == 0
+            first = (in_ptr - in_base) // plane_in
+            assert out_ptr - stream_ptr == first * plane_out
+            done += list(range(lo + first, lo + first + h // size))
+        assert done == list(range(lo, hi))
+        # one record on the compute stream and one wait on the comm stream per round, same event, in order
+        assert [e for e in fake.log if e[0] == "record"] == [("record", 1000 + k, "compute") for k in range(plan.rounds)]
+        assert [e for e in fake.log if e[0] == "wait"] == [("wait", 1000 + k, "comm") for k in range(plan.rounds)]
+        assert len(comm.calls) == plan.rounds and all(c[5] == 0 and c[6] == "comm" for c in comm.calls)
+        per_rank[rank] = (comm.calls, stream_ptr, lo)
+    landed = {p: 0 for p in range(n_planes)}
+    for p in range(*plan.spans[0]):
+        landed[p] += 1                                   # the root's own planes are written in place
+    for k in range(plan.rounds):
+        root_call = per_rank[0][0][k]
+        assert root_call[1] == 0 and root_call[3][0] == 0            # root: nothing sent, nothing received from itself
+        for rank in range(1, world):
+            send_ptr, send_bytes, _, rb, _, _, _ = per_rank[rank][0][k]
+            assert sum(rb) == 0                                        # only the root posts receives
+            assert send_bytes == root_call[3][rank]                    # matched sizes: no rank waits for the other
+            if send_bytes:
+                first = per_rank[rank][2] + (send_ptr - per_rank[rank][1]) // plane_out
+                assert root_call[4][rank] == first * plane_out         # lands at that plane's place in the batch's stream
+                for p in range(first, first + send_bytes // plane_out):
+                    landed[p] += 1
+    assert all(v == 1 for v in landed.values())
+
+
 CTL_WORKER = r'''
 import os, sys
 sys.path.insert(0, %(pkg)r)
