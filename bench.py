@@ -536,16 +536,7 @@ def gather_legs(args, jpegx, multigpu, ctl, rank, world, spans, in_ptr, out_ptr,
 
     def gather_only():
         for k in range(view.rounds):
-            first, count = view.round_of(comm.rank, k)
-            sizes, offs = [0] * view.world, [0] * view.world
-            if comm.rank == 0:
-                for r in range(view.world):
-                    if r == 0 and not loopback:
-                        continue
-                    f, c = view.round_of(r, k)
-                    sizes[r], offs[r] = c * plane_out, f * plane_out
-            send = 0 if (comm.rank == 0 and not loopback) else count * plane_out
-            comm.gather_bytes(out_ptr + (first - lo) * plane_out, send, send_root, sizes, offs, root=0, stream=s_comm)
+            multigpu.ship_round(comm, view, k, out_ptr, send_root, s_comm, root=0, loopback=loopback)
 
     def timed(fn):
         jpegx.check(L.jpegx_device_synchronize(), "sync")

@@ -367,6 +367,26 @@ class GatherPlan:
         return a, min(hi, a + self.chunk) - a
 
 
+def ship_round(comm, plan, k, stream_ptr, root_ptr, comm_stream, root=0, loopback=False):
+    """Round k of the gather: this rank's k-th chunk of planes (its int16 stream starts at ``stream_ptr``) goes to
+    the root, which posts the matching receives at the planes' offsets of ``root_ptr`` -- one grouped
+    ncclSend/ncclRecv on ``comm_stream``.  The root's own planes are already in place (unless ``loopback``)."""
+    rank = comm.rank
+    first, count = plan.round_of(rank, k)
+    out_plane = plan.plane_bytes
+    sizes = [0] * plan.world
+    offs = [0] * plan.world
+    if rank == root:
+        for r in range(plan.world):
+            if r == root and not loopback:
+                continue
+            f, c = plan.round_of(r, k)
+            sizes[r], offs[r] = c * out_plane, f * out_plane
+    send = 0 if (rank == root and not loopback) else count * out_plane
+    comm.gather_bytes(stream_ptr + (first - plan.spans[rank][0]) * out_plane, send, root_ptr, sizes, offs, root=root,
+                      stream=comm_stream)
+
+
 def transform_and_gather(comm, plan, in_ptr, stream_ptr, root_ptr, size, mode, param, flags, compute_stream, comm_stream,
                          events, root=0, loopback=False):
     """Forward-transform the rank's planes (``size`` x ``size`` fp32 each, stacked at ``in_ptr``) in
@@ -391,14 +411,4 @@ def transform_and_gather(comm, plan, in_ptr, stream_ptr, root_ptr, size, mode, p
                                        mode, param, flags, stream=compute_stream)
         jpegx.check(L.jpegx_event_record(events[k].handle, compute_stream), "jpegx_event_record")
         jpegx.check(L.jpegx_stream_wait_event(comm_stream, events[k].handle), "jpegx_stream_wait_event")
-        sizes = [0] * plan.world
-        offs = [0] * plan.world
-        if rank == root:
-            for r in range(plan.world):
-                if r == root and not loopback:
-                    continue                       # own planes are already in place
-                f, c = plan.round_of(r, k)
-                sizes[r], offs[r] = c * out_plane, f * out_plane
-        send = 0 if (rank == root and not loopback) else count * out_plane
-        comm.gather_bytes(stream_ptr + (first - lo_mine) * out_plane, send, root_ptr, sizes, offs, root=root,
-                          stream=comm_stream)
+        ship_round(comm, plan, k, stream_ptr, root_ptr, comm_stream, root=root, loopback=loopback)
