@@ -132,8 +132,8 @@ FWD_VARIANTS = [("auto", 0), ("strip", gpu.F_TUNE_NO_COLUMN_UNITS), ("cols", gpu
                 ("float64 eight lanes", gpu.F_TUNE_F64_KERNEL), ("float64 lane per block", gpu.F_TUNE_F64_KERNEL | gpu.F_TUNE_F64_LANE_PER_BLOCK)]
 
 
-def one_round(rng, tally, size):
-    h = w = size
+def one_round(rng, tally, shape):
+    h, w = shape
     kind = PIXEL_KINDS[int(rng.integers(0, len(PIXEL_KINDS)))]
     mode, param = pick_quantiser(rng)
     tag = "%s %s %g" % (kind, mode, param)
@@ -148,17 +148,17 @@ def one_round(rng, tally, size):
 
     # fused mean-pool prologue: 2x2 and 4x4, uint8 and fp32 inputs
     bs = 2 if rng.random() < 0.7 else 4
-    pooled = oracle.mean_pool(u8, bs).astype(np.float32)                  # exact in fp32 for bs 2, 4
-    wantp = oracle_forward(pooled, mode, param) if h % (8 * bs) == 0 else None
+    pooled = oracle.mean_pool(u8[:h - h % bs, :w - w % bs], bs).astype(np.float32)                  # exact in fp32 for bs 2, 4
+    wantp = oracle_forward(pooled, mode, param) if (h % (8 * bs) == 0 and w % (8 * bs) == 0) else None
     if wantp is not None:
         if gpu.u8_path_ok(w // bs, bs, w, mode, param):
             compare(tally, "forward pooled uint8 bs%d" % bs, gpu.forward_fused_u8(u8, bs, mode, param), wantp, tag)
         compare(tally, "forward pooled fp32 bs%d" % bs, gpu.forward_fused_pooled(f32, bs, mode, param), wantp, tag)
 
     # float64 kernel (any block_size): bs = 3 means on a crop whose size divides
-    hh = (h // 24) * 24
-    if hh >= 24 and rng.random() < 0.3:
-        means = oracle.mean_pool(u8[:hh, :hh], 3)
+    hh, ww = (h // 24) * 24, (w // 24) * 24
+    if hh >= 24 and ww >= 24 and rng.random() < 0.3:
+        means = oracle.mean_pool(u8[:hh, :ww], 3)
         compare(tally, "forward float64 (bs 3 means)", gpu.forward_fused_f64(means, mode, param),
                 oracle_forward_f64(means, mode, param), tag)
 
@@ -229,20 +229,19 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=120.0)
     ap.add_argument("--seed", type=int, default=20261004)
-    ap.add_argument("--sizes", default="1024,2048,4096,520,1096")
+    ap.add_argument("--sizes", default="1024,2048,4096,520,1096,8x8192,4096x8,24x4104,1032x1000,72x264,2048x4096",
+                    help="square sizes or HxW shapes, comma separated (rounded down to multiples of 8)")
     args = ap.parse_args()
     gpu.require_device()
     oracle.build()
     rng = np.random.default_rng(args.seed)
-    sizes = [int(s) for s in args.sizes.split(",")]
+    shapes = [tuple(int(v) - int(v) % 8 for v in (s.split("x") if "x" in s else (s, s))) for s in args.sizes.split(",")]
     tally = Tally()
     t0 = time.time()
     rounds = 0
     last = t0
     while time.time() - t0 < args.seconds:
-        size = sizes[int(rng.integers(0, len(sizes)))]
-        size -= size % 8
-        one_round(rng, tally, size)
+        one_round(rng, tally, shapes[int(rng.integers(0, len(shapes)))])
         rounds += 1
         if time.time() - last > 45:
             v, b = tally.total()
