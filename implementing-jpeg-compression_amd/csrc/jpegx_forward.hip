@@ -972,16 +972,29 @@ __global__ __launch_bounds__(64) void k_forward_fused_u8(const unsigned char *__
     // 8 input rows = 16 KiB, laid out exactly like the fp32 strip (2 KiB rows, strip_swz chunks)
     constexpr int IN_BYTES = (BS == 4) ? STRIP_BYTES : ROWS * ROW_BYTES;
     constexpr int FRONT = IN_BYTES > TILE_BYTES ? IN_BYTES : TILE_BYTES;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[FRONT + SCRATCH_DOUBLES * 8 + 128];
+    // behind the cooperative scratch and the 128-byte patch area: the exact tier's table (C, the luminance table,
+    // the inverse zigzag order -- one LDS-DMA instruction) and, for BS = 4, 128 bytes through which the owner of a
+    // flagged block hands its tile sums to the wave: the tier issues NO vector memory load (under the streaming
+    // load such a load waits for microseconds; k_inverse_fused has the measurement)
+    // (BS = 1 keeps the constant-memory tables: there the 1 KiB and the extra live values cost a wave of occupancy
+    // and 3 % -- 24.3 vs 25.1 Gblocks/s -- while BS = 2 gains 6 % and BS = 4, which also re-read its samples from
+    // memory, 9 %: profiles/r02_ab_u8_exact_tier.txt)
+    constexpr bool TABBED = BS != 1;
+    constexpr int U8_PATCH = FRONT + SCRATCH_DOUBLES * 8, U8_TAB = U8_PATCH + 128, U8_XBLK = U8_TAB + (TABBED ? 1024 : 0);
+    __shared__ __attribute__((aligned(16))) unsigned char lds[U8_XBLK + (BS == 4 ? 128 : 0)];
     double *sA = reinterpret_cast<double *>(lds + FRONT);
     double *sM = sA + 64;
-    int16_t *sP = reinterpret_cast<int16_t *>(lds + FRONT + SCRATCH_DOUBLES * 8);
+    int16_t *sP = reinterpret_cast<int16_t *>(lds + U8_PATCH);
 
     const int lane = threadIdx.x;
     const int g0 = blockIdx.x * 64;
     const bool valid = g0 + lane < nblk;
+    if (TABBED)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(reinterpret_cast<const unsigned char *>(&c_fwd_exact) + lane * 16),
+                                         (__attribute__((address_space(3))) void *)(lds + U8_TAB), 16, 0, 0);
 
     float v[64];
+    unsigned stash[BS == 4 ? 32 : 1];      // BS = 4: the 64 tile sums (<= 4080) as 16-bit pairs, for the exact tier
     if (BS == 4) {
         // SubSampling.execute fused for block_size 4 (the CLI default, compress.py:33): per phase the
         // wave brings in 8 input rows of 2 KiB (lane l of piece j <-> chunk strip_swz(64 j + l) = half
@@ -1024,6 +1037,11 @@ __global__ __launch_bounds__(64) void k_forward_fused_u8(const unsigned char *__
                 for (int c = 0; c < 8; ++c) {
                     v[(ph * 2 + ro) * 8 + c] = (float)sum[c] * 0.0625f;
                     asm volatile("" : "+v"(v[(ph * 2 + ro) * 8 + c]) : : "memory");   // fold now (register pressure)
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    stash[(ph * 2 + ro) * 4 + c] = sum[2 * c] | (sum[2 * c + 1] << 16);
+                    asm volatile("" : "+v"(stash[(ph * 2 + ro) * 4 + c]));           // packed here, not at its use
                 }
             }
         }
@@ -1086,41 +1104,45 @@ __global__ __launch_bounds__(64) void k_forward_fused_u8(const unsigned char *__
     unsigned long long flagged = __ballot(valid && !(worst < 0.5f));
     census(counters, flagged, nblk - g0, lane);
     if (prm.tune & 1) flagged = 0;
-    while (flagged) {   // exact tier, samples re-read from the rows still resident in LDS
-        const int b = __ffsll((long long)flagged) - 1;
-        flagged &= flagged - 1;
+    if (flagged) {      // exact tier: samples from the rows still resident in LDS (BS = 4: from the owner's tile sums)
+        const unsigned char *tab = lds + U8_TAB;
+        const double *tabC = reinterpret_cast<const double *>(tab);
+        const double rq_lane = TABBED ? 1.0 / (double)tab[512 + lane] : c_rq64.v[lane];      // quantizers.py:49 "1.0 / q", same quotient
+        const int pz = TABBED ? (int)tab[576 + lane] : c_zzinv.v[lane];
         const int i = lane >> 3, j = lane & 7;
-        double a;
-        if (BS == 1) {
-            a = (double)lds[i * 512 + b * 8 + j];
-        } else if (BS == 2) {
-            const unsigned char *p0 = lds + (2 * i) * 1024 + b * 16 + 2 * j;
-            a = ((double)p0[0] + (double)p0[1] + (double)p0[1024] + (double)p0[1025]) / 4.0;   // np.mean
-        } else {
-            // block_size 4: the rows are no longer in LDS, re-read the 4 x 4 tile from global memory
-            const int gb = g0 + b;
-            const int byb = gb / wb, bxb = gb - byb * wb;
-            const unsigned char *p0 = in + ((size_t)byb * 32 + 4 * i) * pitch + (size_t)bxb * 32 + 4 * j;
-            unsigned tot = 0;
+        while (flagged) {
+            const int b = __ffsll((long long)flagged) - 1;
+            flagged &= flagged - 1;
+            double a;
+            if (BS == 1) {
+                a = (double)lds[i * 512 + b * 8 + j];
+            } else if (BS == 2) {
+                const unsigned char *p0 = lds + (2 * i) * 1024 + b * 16 + 2 * j;
+                a = ((double)p0[0] + (double)p0[1] + (double)p0[1024] + (double)p0[1025]) / 4.0;   // np.mean
+            } else {
+                // block_size 4: the rows have left LDS; the owner lane publishes its 64 integer tile sums
+                unsigned char *xblk = lds + U8_XBLK;
+                if (lane == b) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const unsigned w = *reinterpret_cast<const unsigned *>(p0 + (size_t)u * pitch);
-                tot += (w & 0xFFu) + ((w >> 8) & 0xFFu) + ((w >> 16) & 0xFFu) + (w >> 24);
+                    for (int c = 0; c < 8; ++c)
+                        *reinterpret_cast<u32x4 *>(xblk + c * 16) = u32x4{stash[4 * c], stash[4 * c + 1], stash[4 * c + 2], stash[4 * c + 3]};
+                }
+                __syncthreads();
+                a = (double)*reinterpret_cast<const unsigned short *>(xblk + lane * 2) / 16.0;       // np.mean
             }
-            a = (double)tot / 16.0;                                                             // np.mean
-        }
-        const double y = coop_fwd_exact(a, sA, sM, lane);
-        const double r = jpegx_quant_ref(y, lane, prm.mode, prm.param, c_rq64.v);
-        sP[c_zzinv.v[lane]] = (int16_t)jpegx_clamp_i16(r);
-        __syncthreads();
-        if (lane == b) {
+            const double y = TABBED ? coop_fwd_exact_tab(a, sA, sM, lane, tabC) : coop_fwd_exact(a, sA, sM, lane);
+            const double r = jpegx_quant_lane(y, lane, prm.mode, prm.param, rq_lane);
+            sP[pz] = (int16_t)jpegx_clamp_i16(r);
+            __syncthreads();
+            if (lane == b) {
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const u32x4 t = *reinterpret_cast<const u32x4 *>(reinterpret_cast<unsigned char *>(sP) + c * 16);
-                pk[c * 4 + 0] = t.x; pk[c * 4 + 1] = t.y; pk[c * 4 + 2] = t.z; pk[c * 4 + 3] = t.w;
+                for (int c = 0; c < 8; ++c) {
+                    const u32x4 t = *reinterpret_cast<const u32x4 *>(reinterpret_cast<unsigned char *>(sP) + c * 16);
+                    pk[c * 4 + 0] = t.x; pk[c * 4 + 1] = t.y; pk[c * 4 + 2] = t.z; pk[c * 4 + 3] = t.w;
+                }
             }
+            __syncthreads();
         }
-        __syncthreads();
     }
 
     __syncthreads();    // the input rows are dead: reuse the front of LDS as the swizzled output tile
