@@ -10,7 +10,6 @@ import subprocess
 import time
 import sys
 
-import numpy as np
 import pytest
 
 from conftest import PKG, REPO
