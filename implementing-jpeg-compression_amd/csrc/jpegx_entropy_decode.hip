@@ -11,8 +11,8 @@
 //   2. parse       one thread per candidate parses ONE block from there and records at which candidate the
 //                  next block would start (false candidates -- zero bytes inside a block's amplitude bits --
 //                  parse garbage; they are simply never reached);
-//   3. jump tables J_k[c] = the candidate 2^k blocks behind candidate c (pointer doubling, log2(nblocks) passes);
-//   4. starts      block i starts at the candidate reached from position 0 by following the bits of i;
+//   3. jump tables J_k[c] = the candidate 4^k blocks behind candidate c (radix-4 pointer jumping, log4(nblocks) passes);
+//   4. starts      block i starts at the candidate reached from position 0 by following the base-4 digits of i;
 //   5. decode      lane per block, values into an LDS tile, coalesced 1 KiB stores into the zigzag stream.
 // Steps 1-4 read the stream twice and touch ~1.4 candidates per block; the result equals the host parser's.
 // One difference on DAMAGED input: the host parser skips the padding bits unread, so a stream whose padding has
@@ -31,17 +31,6 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr unsigned NIL = 0xFFFFFFFFu;
 constexpr int CHUNK = 4096;              // bytes per workgroup of 256 threads in the candidate passes
 __device__ __forceinline__ int tile_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
-
-// 32 bits of the stream starting at bit position `bit` (MSB first).  The buffer is dword aligned and at
-// least 8 readable bytes longer than the stream.
-__device__ __forceinline__ unsigned peek32(const unsigned *__restrict__ words, unsigned long long bit)
-{
-    const unsigned long long byte = bit >> 3;
-    const unsigned w0 = words[byte >> 2], w1 = words[(byte >> 2) + 1];
-    const unsigned long long v = ((unsigned long long)__builtin_bswap32(w0) << 32) | __builtin_bswap32(w1);
-    const unsigned sh = (unsigned)(byte & 3) * 8u + (unsigned)(bit & 7);
-    return (unsigned)((v << sh) >> 32);
-}
 
 // number of candidate positions contributed by bytes [q0, q0+16): position q+1 for every zero byte q,
 // plus position 0 for the very first thread
@@ -131,40 +120,57 @@ __global__ __launch_bounds__(256) void k_dec_scatter(const unsigned char *__rest
     }
 }
 
-// parse one block starting at byte `p`: returns the byte position behind it, or NIL if what is there is
-// not a block (illegal code, more than 64 coefficients, or the stream ends inside it).  With `tile` != null
+// parse one block starting at byte `p` (p <= nbytes): returns the byte position behind it, or NIL if what is
+// there is not a block (illegal code, more than 64 coefficients, or the stream ends inside it).  With `tile` != null
 // the coefficients are written into the lane's row of the LDS tile (which must be zero).
+// These loops are ALU-bound (every lane walks its own block: ~40 dependent steps on noise), so the step is kept
+// short: 32-bit positions relative to the block's first dword, the stream seen through two big-endian dword
+// registers and one v_alignbit_b32, a new dword shifted in whenever the position crosses a dword boundary (a code
+// is at most 23 bits: at most once per code) and requested one step ahead.  The buffer is dword aligned and at
+// least 16 readable bytes longer than the stream.
 template <bool WRITE>
 __device__ __forceinline__ unsigned parse_block(const unsigned *__restrict__ words, unsigned long long nbits, unsigned p,
                                                 unsigned char *tile, int row)
 {
-    unsigned long long bit = (unsigned long long)p * 8u;
-    int n = 0;
+    const unsigned long long left = nbits - (unsigned long long)p * 8u;
+    const unsigned *wp = words + (p >> 2);
+    const unsigned first = (p & 3u) * 8u;                                  // the block's first bit, counted from wp[0]
+    const unsigned end = first + (left > 0x7FFFFF00ull ? 0x7FFFFF00u : (unsigned)left);   // the stream's last bit + 1, same origin
+    unsigned pos = first, wi = 0;
+    unsigned hi = __builtin_bswap32(wp[0]), lo = __builtin_bswap32(wp[1]), ahead = wp[2];
+    unsigned n = 0, ret = NIL;
+    // one exit test per step and everything else by selects: with an early return at every check the compiler
+    // spends half of the loop's instructions moving registers between the divergent paths
     for (int it = 0; it < 66; ++it) {
-        if (bit + 8 > nbits) return NIL;
-        const unsigned w = peek32(words, bit);
+        const unsigned sh = pos & 31u;
+        const unsigned fun = __builtin_amdgcn_alignbit(hi, lo, 32u - sh);   // (hi:lo) >> (32 - sh); sh = 0 needs hi itself
+        const unsigned w = sh ? fun : hi;
         const unsigned run = w >> 28, size = (w >> 24) & 15u;
-        if (size == 0) {
-            bit += 8;
-            if (run == 0) return (unsigned)((bit + 7) >> 3);       // end marker, then the zero padding
-            if (run != 15) return NIL;                             // zero size with a non-terminal run
-            n += 15;                                               // a chain code is FIFTEEN zeros (util.py:134-154)
-            if (n > 64) return NIL;
-            continue;
-        }
-        if (bit + 8 + size > nbits) return NIL;
-        n += (int)run;
-        if (n >= 64) return NIL;
-        if (WRITE) {
+        const bool zero = size == 0;
+        const bool eob = (w >> 24) == 0;                                    // end marker, then the zero padding
+        const unsigned nn = n + (zero ? 15u : run);                         // a chain code is FIFTEEN zeros (util.py:134-154)
+        // not a block: the stream ends inside the code, a zero size with a run other than 0 / 15, a 65th coefficient
+        const bool bad = (pos + 8 + size > end) | (zero & (run != 15u) & !eob) | (!eob & (nn > (zero ? 64u : 63u)));
+        if (WRITE && !zero && !bad) {
             const unsigned bits = (w << 8) >> (32 - size);
             const unsigned mag = bits & ((1u << (size - 1)) - 1u);
-            const int amp = (bits >> (size - 1)) ? (int)mag : -(int)mag;                // sign bit '1' = positive
-            *reinterpret_cast<int16_t *>(tile + tile_off(row, n >> 3) + (n & 7) * 2) = (int16_t)amp;
+            const int amp = (bits >> (size - 1)) ? (int)mag : -(int)mag;                    // sign bit '1' = positive
+            *reinterpret_cast<int16_t *>(tile + tile_off(row, (int)(nn >> 3)) + (nn & 7u) * 2) = (int16_t)amp;
         }
-        ++n;
-        bit += 8 + size;
+        if (bad | eob) {
+            ret = bad ? NIL : p + ((pos - first + 8 + 7) >> 3);
+            break;
+        }
+        n = nn + (zero ? 0u : 1u);
+        pos += 8 + size;
+        if ((pos >> 5) != wi) {                                            // crossed into the next dword: shift it in
+            ++wi;
+            hi = lo;
+            lo = __builtin_bswap32(ahead);
+            ahead = wp[wi + 2];                                            // pos <= end: at most 11 bytes into the slack
+        }
     }
-    return NIL;
+    return ret;
 }
 
 __global__ __launch_bounds__(256) void k_dec_parse(const unsigned *__restrict__ words, size_t nbytes, const unsigned *__restrict__ cand_pos,
@@ -189,12 +195,16 @@ __global__ __launch_bounds__(256) void k_dec_parse(const unsigned *__restrict__ 
     J0[c] = nxt;
 }
 
+// J_{k+1}[c] = the candidate 4^(k+1) blocks behind c = four steps of J_k (radix-4 pointer jumping: half as many
+// passes -- and launches, which is what a 4096 x 4096 band's decode is made of -- as doubling)
 __global__ __launch_bounds__(256) void k_dec_jump(const unsigned *__restrict__ Jk, unsigned *__restrict__ Jk1, unsigned ncand)
 {
     const unsigned c = blockIdx.x * 256u + threadIdx.x;
     if (c >= ncand) return;
-    const unsigned a = Jk[c];
-    Jk1[c] = a == NIL ? NIL : Jk[a];
+    unsigned a = Jk[c];
+#pragma unroll
+    for (int step = 0; step < 3; ++step) a = (a == NIL) ? NIL : Jk[a];
+    Jk1[c] = a;
 }
 
 __global__ __launch_bounds__(256) void k_dec_starts(const unsigned *__restrict__ J, int levels, unsigned ncand,
@@ -204,8 +214,10 @@ __global__ __launch_bounds__(256) void k_dec_starts(const unsigned *__restrict__
     const unsigned i = blockIdx.x * 256u + threadIdx.x;
     if (i >= nblocks) return;
     unsigned cur = 0;                                   // candidate 0 = position 0
-    for (int k = 0; k < levels && cur != NIL; ++k)
-        if ((i >> k) & 1u) cur = J[(size_t)k * ncand + cur];
+    for (int k = 0; k < levels && cur != NIL; ++k) {    // follow the base-4 digits of i
+        const unsigned digit = (i >> (2 * k)) & 3u;
+        for (unsigned d = 0; d < digit && cur != NIL; ++d) cur = J[(size_t)k * ncand + cur];
+    }
     const unsigned p = cur == NIL ? NIL : cand_pos[cur];
     if (p == NIL || p >= nbytes) atomicOr(&head[1], 1u);            // fewer than nblocks blocks in the stream
     start_pos[i] = p;
@@ -237,10 +249,10 @@ __global__ __launch_bounds__(64) void k_dec_blocks(const unsigned *__restrict__ 
 
 namespace jpegx_decode {
 
-int levels_for(long long nblocks)
+int levels_for(long long nblocks)          // base-4 digits of the largest block index
 {
     int l = 1;
-    while ((1ll << l) < nblocks) ++l;
+    while ((1ll << (2 * l)) < nblocks) ++l;
     return l;
 }
 
