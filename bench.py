@@ -64,6 +64,8 @@ def parse_args():
                     help="untimed launches before the W warm-up steps so that the GPU leaves its idle clocks")
     ap.add_argument("--gather-chunk", type=int, default=4, help="planes per send/recv round of the overlapped gather")
     ap.add_argument("--gather-timeout", type=float, default=150.0, help="seconds the gather legs may take before rank 0 reports without them")
+    ap.add_argument("--comm-timeout", type=float, default=60.0,
+                    help="deadline (s) of RCCL communicator creation and of each gather round's enqueue (libjpegx returns JPEGX_E_TIMEOUT)")
     ap.add_argument("--share-device", action="store_true",
                     help="rehearsal on ONE GPU: every rank uses GPU 0 and a 1-rank RCCL communicator "
                          "(loop-back send/recv); exercises launcher, control plane, events and streams")
@@ -254,10 +256,31 @@ def config4(jpegx, kind, iters, verify, planes=16):
 
 
 # --------------------------------------------------------------------------------------------------
+GATHER_FAILED_STATUS = 3       # exit status of every rank when the exchange (gather legs) failed or timed out
+
+
+def leave_after_failed_exchange(rank, emit, line):
+    """The exchange failed or hung: rank 0 prints the line (the compute-phase result in it is complete and valid,
+    the failure is recorded under "gather"), then EVERY rank leaves with GATHER_FAILED_STATUS -- the job's return
+    code must show the failed exchange.  os._exit: streams may hold RCCL kernels that will never finish, nothing
+    may wait for them.  Ranks other than 0 hold back a moment so that a launcher that tears the job down at the
+    first non-zero exit (torch.distributed.run) does so after the line is out."""
+    if rank == 0:
+        emit(line)
+    else:
+        time.sleep(2.0)
+    os._exit(GATHER_FAILED_STATUS)
+
+
 def main():
     args = parse_args()
     from jpegx import multigpu
     in_job = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if in_job or args.gpus > 1:
+        # before anything loads HIP or RCCL, and also when an external launcher (torch.distributed.run, the
+        # driver's way) started this rank: dmabuf IPC for RCCL peer-to-peer, rocm_smi's mutex process-local
+        # (see jpegx.multigpu.rank_process_env for the why of each)
+        multigpu.rank_process_env()
     if not in_job and args.gpus > 1:
         # bare `python bench.py --gpus N`: become the launcher (nothing has touched the GPU yet)
         sys.exit(multigpu.launch_ranks(args.gpus, [os.path.abspath(__file__)] + sys.argv[1:]))
@@ -302,12 +325,11 @@ def run(args, rank, local_rank, world, ctl, emit):
                 "max_rank": t, "launcher": os.environ.get("JPEGX_LAUNCHER", "external")}
         if args.dry_run_stall > 0:
             # rehearsal of the watchdog that guards the gather legs of a real run: the "exchange" below never
-            # comes back in time, rank 0 must still print its line and every rank must leave with status 0
+            # comes back in time; rank 0 must still print its line, and then every rank leaves with a NON-ZERO
+            # status so that the launcher's (and the driver's) return code shows the failed exchange
             def give_up():
                 line["gather"] = {"error": "gather legs did not finish within %.0f s; compute-phase result kept" % args.gather_timeout}
-                if rank == 0:
-                    emit(line)
-                os._exit(0)
+                leave_after_failed_exchange(rank, emit, line)
             guarded(args.gather_timeout, give_up, lambda: time.sleep(args.dry_run_stall))
         if rank == 0:
             emit(line)
@@ -355,9 +377,11 @@ def run(args, rank, local_rank, world, ctl, emit):
 
     # clock spin-up (untimed, not part of W): the device ramps from idle clocks over the first ~10 ms
     t_spin = time.perf_counter()
+    spin_launches = 0
     while (time.perf_counter() - t_spin) * 1e3 < args.spinup_ms:
         step()
         jpegx.check(L.jpegx_stream_synchronize(stream), "sync")
+        spin_launches += 1
     for _ in range(args.warmup):
         step()
     barrier()
@@ -434,6 +458,12 @@ def run(args, rank, local_rank, world, ctl, emit):
                      "algorithmic_bytes_per_launch": BYTES_PER_BLOCK * blocks_per_step},
         "exact_tier_block_fraction": round(exact_frac, 5),
         "verified_vs_oracle": verified,
+        # what ran when (every launch of this process, in order): untimed clock spin-up, the W declared warm-up
+        # steps, the K timed steps (value and roofline come from these alone), one instrumented census launch on at
+        # most 16 planes, then host-side verification; the configs / cpu_baseline legs follow at N = 1
+        "launches": {"spinup_ms": args.spinup_ms, "spinup": spin_launches, "warmup": args.warmup, "timed": args.steps,
+                     "census": 1, "note": "spin-up launches are full steps, untimed and not part of `warmup`; "
+                                          "cpu_baseline is a single-core host loop during which the GPU idles"},
         "device": jpegx.device_name(device),
     }
     # --- the one exchange of the path: RCCL gather of the int16 stream to rank 0 -------------------
@@ -442,13 +472,9 @@ def run(args, rank, local_rank, world, ctl, emit):
     # prints the line, with the timeout recorded under "gather", and every rank leaves.
     if gathering:
         def give_up():
-            result["gather"] = {"error": "gather legs did not finish within %.0f s; compute-phase result kept" % args.gather_timeout}
-            if rank == 0:
-                emit(result)
-            # every rank leaves with status 0: the compute-phase measurement is complete and valid, the failed
-            # exchange is recorded in the line itself -- a non-zero status would make the launcher tear the job
-            # down (possibly before rank 0 has printed) and report the whole run as failed
-            os._exit(0)
+            result["gather"] = {"error": "gather legs did not finish within %.0f s; compute-phase result kept" % args.gather_timeout,
+                                "rsmi_shm": multigpu.rsmi_shm_report()}
+            leave_after_failed_exchange(rank, emit, result)
 
         def legs():
             try:
@@ -461,6 +487,18 @@ def run(args, rank, local_rank, world, ctl, emit):
             result["gather"] = gather
         if end_to_end is not None:
             result["end_to_end"] = end_to_end
+        # every rank reaches the same verdict (the votes inside gather_legs are collective); an exchange that failed
+        # -- as opposed to one that was not asked for -- ends the job with a non-zero status, line printed first
+        failed = gather is None or "error" in gather or gather.get("root_copy_ok") is False \
+            or "error" in gather.get("compressed", {}) or gather.get("compressed", {}).get("root_copy_ok") is False
+        try:
+            failed = bool(any(ctl.allgather(bool(failed))))
+        except multigpu.ControlPlaneError:
+            failed = True
+        if failed:
+            if gather is None:
+                result["gather"] = {"error": "gather legs returned nothing"}
+            leave_after_failed_exchange(rank, emit, result)
     if rank == 0 and world == 1:
         if not args.no_configs:
             # free the batch first: the legs below allocate their own planes
@@ -509,21 +547,37 @@ def gather_legs(args, jpegx, multigpu, ctl, rank, world, spans, in_ptr, out_ptr,
         err = "%s: %s" % (type(exc).__name__, str(exc)[:300])
     if not ctl.all_ok(err is None):
         return {"error": "setup failed on some rank: %s" % ctl.allgather(err)}, None
+    # the 128-byte id: made on rank 0 under try, voted on, and only then broadcast -- a failure to make it must not
+    # leave the other ranks waiting in the broadcast
+    ident = None
+    try:
+        if rank == 0 or loopback:
+            ident = multigpu.NativeComm.unique_id()
+    except Exception as exc:
+        err = "%s: %s" % (type(exc).__name__, str(exc)[:300])
+    if not ctl.all_ok(err is None):
+        return {"error": "ncclGetUniqueId: %s" % ctl.allgather(err)}, None
+    t_id = time.perf_counter()
+    if not loopback:
+        ident = ctl.bcast_bytes(ident)
+    sys.stderr.write("[jpegx comm rank %d/%d pid %d] id-broadcast done in %.3f s\n" % (rank, world, os.getpid(), time.perf_counter() - t_id))
+    sys.stderr.flush()
+    rsmi_shm = multigpu.rsmi_shm_report()
     try:
         if loopback:
-            comm = multigpu.NativeComm(1, 0, lambda ident: ident)
+            comm = multigpu.NativeComm(1, 0, timeout_s=args.comm_timeout, ident=ident)
             view = multigpu.GatherPlan(planes, 1, plane_out, args.gather_chunk)
             view.spans = [(lo, hi)]                      # keep batch plane numbering
             send_root = root_ptr
         else:
-            comm = multigpu.NativeComm(world, rank, ctl.bcast_bytes)
+            comm = multigpu.NativeComm(world, rank, timeout_s=args.comm_timeout, ident=ident)
             view, send_root = plan, root_ptr
         reported = comm.count()
     except Exception as exc:
         err = "%s: %s" % (type(exc).__name__, str(exc)[:300])
         reported = -1
     if not ctl.all_ok(err is None):
-        return {"error": "RCCL communicator: %s" % ctl.allgather(err)}, None
+        return {"error": "RCCL communicator: %s" % ctl.allgather(err), "rsmi_shm": rsmi_shm}, None
     counts = ctl.allgather(reported)
 
     def sync_all():
@@ -538,11 +592,23 @@ def gather_legs(args, jpegx, multigpu, ctl, rank, world, spans, in_ptr, out_ptr,
         for k in range(view.rounds):
             multigpu.ship_round(comm, view, k, out_ptr, send_root, s_comm, root=0, loopback=loopback)
 
+    class ExchangeAborted(RuntimeError):
+        pass
+
     def timed(fn):
+        """One timed pass.  The rank-local enqueue runs under try and is followed by an all-ranks vote BEFORE anybody
+        waits for the transfers: a rank that failed while enqueueing (its sends will never be matched) makes every
+        rank skip the wait and leave, instead of the others sitting in sync_all() until the watchdog fires."""
         jpegx.check(L.jpegx_device_synchronize(), "sync")
         ctl.barrier()
         t0 = time.perf_counter()
-        fn()
+        err = None
+        try:
+            fn()
+        except Exception as exc:
+            err = "%s: %s" % (type(exc).__name__, str(exc)[:300])
+        if not ctl.all_ok(err is None):
+            raise ExchangeAborted("enqueue failed on some rank: %s" % ctl.allgather(err))
         sync_all()
         t = time.perf_counter() - t0
         return ctl.allreduce_max(t)
@@ -575,6 +641,8 @@ def gather_legs(args, jpegx, multigpu, ctl, rank, world, spans, in_ptr, out_ptr,
                   "xgmi_bound_GBps": XGMI_ROOT_INGRESS_GBPS,
                   "frac_of_xgmi_bound": None if loopback else round(into_root / t_g / 1e9 / XGMI_ROOT_INGRESS_GBPS, 4),
                   "rccl_ranks_reported": counts, "chunk_planes": args.gather_chunk, "rounds": view.rounds, "root_copy_ok": ok,
+                  "comm_timeout_s": args.comm_timeout, "rsmi_mutex_thread_only": os.environ.get("RSMI_MUTEX_THREAD_ONLY"),
+                  "rsmi_shm_stale": [r["file"] for r in rsmi_shm if r.get("stale")],
                   "transport": "loop-back rehearsal on one GPU (1-rank communicator per process)" if loopback else
                                "jpegx_comm_gather_bytes: grouped ncclSend/ncclRecv of raw bytes, comm stream only, data already computed"}
         e2e = {"ms": round(t_e2e * 1e3, 3), "Mblocks_per_s": round(total_blocks_per_step / t_e2e / 1e6, 2),

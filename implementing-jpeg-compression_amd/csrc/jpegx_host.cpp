@@ -93,27 +93,42 @@ extern "C" int jpegx_host_entropy_decode(const uint8_t *h_bytes, size_t nbytes, 
 // reused.  ncclGather-style: grouped ncclSend (every rank) / ncclRecv (root, one per rank) of raw
 // bytes, enqueued on the caller's stream.  The unique id is exchanged by the caller (any side
 // channel: torch.distributed, MPI, a file).
+//
+// Nothing in here may block without a deadline (round 3): the communicator is created NON-BLOCKING
+// (ncclCommInitRankConfig with blocking = 0) and every RCCL call that may answer ncclInProgress is
+// followed by a poll of ncclCommGetAsyncError against a deadline, so a peer that never arrives, or an
+// RCCL initialisation that sits in one of its own dependencies (rocm_smi's process-shared mutex, see
+// DESIGN.md section 6), ends in JPEGX_E_TIMEOUT naming the phase instead of a silent hang.  With
+// JPEGX_COMM_LOG=1 every phase is logged to stderr with a time stamp.
 // ------------------------------------------------------------------------------------------------
 #include <dlfcn.h>
+#include <stdlib.h>
 #include <string.h>
+#include <time.h>
+#include <unistd.h>
+
+#include <rccl/rccl.h>   // types and constants only: every function is bound with dlsym
 
 namespace {
 
-typedef struct { char internal[128]; } rccl_unique_id;
-typedef int (*fn_get_unique_id)(rccl_unique_id *);
-typedef int (*fn_comm_init_rank)(void **, int, rccl_unique_id, int);
-typedef int (*fn_comm_destroy)(void *);
-typedef int (*fn_comm_count)(void *, int *);
-typedef int (*fn_send)(const void *, size_t, int, int, void *, void *);
-typedef int (*fn_recv)(void *, size_t, int, int, void *, void *);
-typedef int (*fn_group)(void);
-typedef const char *(*fn_error_string)(int);
+typedef ncclResult_t (*fn_get_unique_id)(ncclUniqueId *);
+typedef ncclResult_t (*fn_comm_init_rank)(ncclComm_t *, int, ncclUniqueId, int);
+typedef ncclResult_t (*fn_comm_init_rank_config)(ncclComm_t *, int, ncclUniqueId, int, ncclConfig_t *);
+typedef ncclResult_t (*fn_comm_async_error)(ncclComm_t, ncclResult_t *);
+typedef ncclResult_t (*fn_comm_op)(ncclComm_t);
+typedef ncclResult_t (*fn_comm_count)(const ncclComm_t, int *);
+typedef ncclResult_t (*fn_send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
+typedef ncclResult_t (*fn_recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
+typedef ncclResult_t (*fn_group)(void);
+typedef const char *(*fn_error_string)(ncclResult_t);
 
 struct Rccl {
     void *handle = nullptr;
     fn_get_unique_id get_unique_id = nullptr;
     fn_comm_init_rank comm_init_rank = nullptr;
-    fn_comm_destroy comm_destroy = nullptr;
+    fn_comm_init_rank_config comm_init_rank_config = nullptr;
+    fn_comm_async_error comm_async_error = nullptr;
+    fn_comm_op comm_destroy = nullptr, comm_abort = nullptr, comm_finalize = nullptr;
     fn_comm_count comm_count = nullptr;
     fn_send send = nullptr;
     fn_recv recv = nullptr;
@@ -141,7 +156,11 @@ int load_rccl()
     r.handle = h;
     r.get_unique_id = (fn_get_unique_id)dlsym(h, "ncclGetUniqueId");
     r.comm_init_rank = (fn_comm_init_rank)dlsym(h, "ncclCommInitRank");
-    r.comm_destroy = (fn_comm_destroy)dlsym(h, "ncclCommDestroy");
+    r.comm_init_rank_config = (fn_comm_init_rank_config)dlsym(h, "ncclCommInitRankConfig");
+    r.comm_async_error = (fn_comm_async_error)dlsym(h, "ncclCommGetAsyncError");
+    r.comm_destroy = (fn_comm_op)dlsym(h, "ncclCommDestroy");
+    r.comm_abort = (fn_comm_op)dlsym(h, "ncclCommAbort");
+    r.comm_finalize = (fn_comm_op)dlsym(h, "ncclCommFinalize");
     r.comm_count = (fn_comm_count)dlsym(h, "ncclCommCount");
     r.send = (fn_send)dlsym(h, "ncclSend");
     r.recv = (fn_recv)dlsym(h, "ncclRecv");
@@ -159,17 +178,75 @@ int load_rccl()
 int rccl_fail(const char *what, int code)
 {
     char buf[300];
-    snprintf(buf, sizeof(buf), "%s failed: %s", what, g_rccl.error_string ? g_rccl.error_string(code) : "RCCL error");
+    snprintf(buf, sizeof(buf), "%s failed: %s", what, g_rccl.error_string ? g_rccl.error_string((ncclResult_t)code) : "RCCL error");
     jpegx_internal_set_error(buf);
     return JPEGX_E_HIP;
 }
 
+double now_s()
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
 struct Comm {
-    void *nccl;
+    ncclComm_t nccl;
     int nranks, rank;
+    bool nonblocking;
+    double timeout_s;       // deadline of every later wait on this communicator
+    double t0;              // creation time: log stamps are relative to it
+    long rounds;            // gather rounds issued so far (the first one sets up the connections)
 };
 
-const int kNcclUint8 = 1;
+bool comm_log_on()
+{
+    const char *e = getenv("JPEGX_COMM_LOG");
+    return e && *e && strcmp(e, "0") != 0;
+}
+
+void comm_log(int rank, int nranks, double t0, const char *phase, const char *detail = "")
+{
+    if (!comm_log_on()) return;
+    fprintf(stderr, "[jpegx comm rank %d/%d pid %d +%.3fs] %s%s\n", rank, nranks, (int)getpid(), now_s() - t0, phase, detail);
+    fflush(stderr);
+}
+
+double default_timeout_s()
+{
+    const char *e = getenv("JPEGX_COMM_TIMEOUT_S");
+    const double v = e ? atof(e) : 0.0;
+    return v > 0.0 ? v : 120.0;
+}
+
+// Wait until the communicator has left ncclInProgress, at most until `deadline`.  JPEGX_OK, JPEGX_E_TIMEOUT
+// (message names `phase`) or JPEGX_E_HIP (RCCL's own error).
+int wait_ready(ncclComm_t c, double deadline, const char *phase, int rank, int nranks)
+{
+    if (!g_rccl.comm_async_error) return JPEGX_OK;
+    useconds_t nap = 50;
+    for (;;) {
+        ncclResult_t state = ncclSuccess;
+        const ncclResult_t e = g_rccl.comm_async_error(c, &state);
+        if (e != ncclSuccess) return rccl_fail("ncclCommGetAsyncError", e);
+        if (state == ncclSuccess) return JPEGX_OK;
+        if (state != ncclInProgress) {
+            char what[120];
+            snprintf(what, sizeof(what), "RCCL (%s, rank %d of %d)", phase, rank, nranks);
+            return rccl_fail(what, state);
+        }
+        if (now_s() > deadline) {
+            char buf[300];
+            snprintf(buf, sizeof(buf), "RCCL %s did not complete before the deadline on rank %d of %d (still ncclInProgress)", phase, rank, nranks);
+            jpegx_internal_set_error(buf);
+            return JPEGX_E_TIMEOUT;
+        }
+        usleep(nap);
+        if (nap < 2000) nap *= 2;
+    }
+}
+
+const ncclDataType_t kBytes = ncclUint8;
 
 }  // namespace
 
@@ -182,35 +259,80 @@ int jpegx_comm_unique_id(void *id128)
     if (!id128) return fail("null id buffer");
     int rc = load_rccl();
     if (rc) return rc;
-    rccl_unique_id id;
-    int e = g_rccl.get_unique_id(&id);
+    ncclUniqueId id;
+    const ncclResult_t e = g_rccl.get_unique_id(&id);
     if (e) return rccl_fail("ncclGetUniqueId", e);
     memcpy(id128, id.internal, 128);
     return JPEGX_OK;
 }
 
-int jpegx_comm_create(jpegx_comm_t *comm, int nranks, int rank, const void *id128)
+int jpegx_comm_create_deadline(jpegx_comm_t *comm, int nranks, int rank, const void *id128, double timeout_s)
 {
     if (!comm || !id128) return fail("null pointer");
     if (nranks < 1 || rank < 0 || rank >= nranks) return fail("bad rank / nranks");
     int rc = load_rccl();
     if (rc) return rc;
-    rccl_unique_id id;
+    if (!(timeout_s > 0.0)) timeout_s = default_timeout_s();
+    ncclUniqueId id;
     memcpy(id.internal, id128, 128);
-    void *c = nullptr;
-    int e = g_rccl.comm_init_rank(&c, nranks, id, rank);   // binds to the calling thread's current HIP device
-    if (e) return rccl_fail("ncclCommInitRank", e);
-    *comm = new Comm{c, nranks, rank};
+    const double t0 = now_s();
+    ncclComm_t c = nullptr;
+    const bool nb = g_rccl.comm_init_rank_config && g_rccl.comm_async_error;
+    comm_log(rank, nranks, t0, "init-enter", nb ? " (ncclCommInitRankConfig, blocking = 0)" : " (ncclCommInitRank, blocking: this librccl has no config entry)");
+    if (nb) {
+        ncclConfig_t cfg = NCCL_CONFIG_INITIALIZER;
+        cfg.blocking = 0;
+        const ncclResult_t e = g_rccl.comm_init_rank_config(&c, nranks, id, rank, &cfg);   // binds to the calling thread's current HIP device
+        if (e != ncclSuccess && e != ncclInProgress) return rccl_fail("ncclCommInitRankConfig", e);
+        rc = wait_ready(c, t0 + timeout_s, "communicator creation (ncclCommInitRankConfig)", rank, nranks);
+        if (rc) {
+            comm_log(rank, nranks, t0, "init-FAILED: ", rc == JPEGX_E_TIMEOUT ? "deadline passed" : "RCCL error");
+            // no ncclCommAbort here: it joins RCCL's init thread, which is the one that is stuck; the handle is
+            // leaked and the caller is expected to leave the process
+            return rc;
+        }
+    } else {
+        const ncclResult_t e = g_rccl.comm_init_rank(&c, nranks, id, rank);
+        if (e) return rccl_fail("ncclCommInitRank", e);
+    }
+    comm_log(rank, nranks, t0, "init-exit");
+    *comm = new Comm{c, nranks, rank, nb, timeout_s, t0, 0};
     return JPEGX_OK;
+}
+
+int jpegx_comm_create(jpegx_comm_t *comm, int nranks, int rank, const void *id128)
+{
+    return jpegx_comm_create_deadline(comm, nranks, rank, id128, 0.0);
 }
 
 int jpegx_comm_destroy(jpegx_comm_t comm)
 {
     if (!comm) return JPEGX_OK;
     Comm *c = static_cast<Comm *>(comm);
-    int e = g_rccl.comm_destroy(c->nccl);
+    ncclResult_t e = ncclSuccess;
+    if (c->nonblocking && g_rccl.comm_finalize) {
+        // a non-blocking communicator is flushed first (ncclCommFinalize -> poll), then freed locally
+        e = g_rccl.comm_finalize(c->nccl);
+        if (e == ncclSuccess || e == ncclInProgress) {
+            if (wait_ready(c->nccl, now_s() + c->timeout_s, "ncclCommFinalize", c->rank, c->nranks) == JPEGX_OK) e = g_rccl.comm_destroy(c->nccl);
+            else e = g_rccl.comm_abort ? g_rccl.comm_abort(c->nccl) : ncclInternalError;
+        }
+    } else {
+        e = g_rccl.comm_destroy(c->nccl);
+    }
+    comm_log(c->rank, c->nranks, c->t0, "destroyed");
     delete c;
     return e ? rccl_fail("ncclCommDestroy", e) : JPEGX_OK;
+}
+
+int jpegx_comm_abort(jpegx_comm_t comm)
+{
+    if (!comm) return JPEGX_OK;
+    Comm *c = static_cast<Comm *>(comm);
+    const ncclResult_t e = g_rccl.comm_abort ? g_rccl.comm_abort(c->nccl) : g_rccl.comm_destroy(c->nccl);
+    comm_log(c->rank, c->nranks, c->t0, "aborted");
+    delete c;
+    return e ? rccl_fail("ncclCommAbort", e) : JPEGX_OK;
 }
 
 int jpegx_comm_count(jpegx_comm_t comm, int *nranks)
@@ -221,7 +343,7 @@ int jpegx_comm_count(jpegx_comm_t comm, int *nranks)
         jpegx_internal_set_error("librccl.so lacks ncclCommCount");
         return JPEGX_E_UNSUPPORTED;
     }
-    int e = g_rccl.comm_count(c->nccl, nranks);      // what RCCL itself believes, not what we passed in
+    const ncclResult_t e = g_rccl.comm_count(c->nccl, nranks);      // what RCCL itself believes, not what we passed in
     return e ? rccl_fail("ncclCommCount", e) : JPEGX_OK;
 }
 
@@ -233,16 +355,28 @@ int jpegx_comm_gather_bytes(jpegx_comm_t comm, const void *d_send, size_t send_b
     if (root < 0 || root >= c->nranks) return fail("bad root rank");
     if (c->rank == root && (!d_recv || !recv_bytes || !recv_offsets)) return fail("root needs receive buffer, sizes and offsets");
     if (send_bytes && !d_send) return fail("null send buffer");
-    int e = g_rccl.group_start();
+    const bool first = c->rounds++ == 0;
+    if (first) comm_log(c->rank, c->nranks, c->t0, "first-round enter (connection setup happens here)");
+    hipStream_t st = (hipStream_t)stream;
+    ncclResult_t e = g_rccl.group_start();
     if (e) return rccl_fail("ncclGroupStart", e);
     if (c->rank == root)
-        for (int r = 0; r < c->nranks && !e; ++r)
+        for (int r = 0; r < c->nranks && (e == ncclSuccess || e == ncclInProgress); ++r)
             if (recv_bytes[r])
-                e = g_rccl.recv(static_cast<char *>(d_recv) + recv_offsets[r], recv_bytes[r], kNcclUint8, r, c->nccl, stream);
-    if (!e && send_bytes) e = g_rccl.send(d_send, send_bytes, kNcclUint8, root, c->nccl, stream);
-    int e2 = g_rccl.group_end();
-    if (e) return rccl_fail("ncclSend/ncclRecv", e);
-    if (e2) return rccl_fail("ncclGroupEnd", e2);
+                e = g_rccl.recv(static_cast<char *>(d_recv) + recv_offsets[r], recv_bytes[r], kBytes, r, c->nccl, st);
+    if ((e == ncclSuccess || e == ncclInProgress) && send_bytes) e = g_rccl.send(d_send, send_bytes, kBytes, root, c->nccl, st);
+    const ncclResult_t e2 = g_rccl.group_end();
+    if (e != ncclSuccess && e != ncclInProgress) return rccl_fail("ncclSend/ncclRecv", e);
+    if (e2 != ncclSuccess && e2 != ncclInProgress) return rccl_fail("ncclGroupEnd", e2);
+    if (c->nonblocking) {
+        // the group is ENQUEUED once the communicator reports ncclSuccess again (the transfer itself runs on `stream`)
+        const int rc = wait_ready(c->nccl, now_s() + c->timeout_s, first ? "first gather round (connection setup)" : "gather round (enqueue)", c->rank, c->nranks);
+        if (rc) {
+            comm_log(c->rank, c->nranks, c->t0, first ? "first-round FAILED" : "round FAILED");
+            return rc;
+        }
+    }
+    if (first) comm_log(c->rank, c->nranks, c->t0, "first-round enqueued");
     return JPEGX_OK;
 }
 

@@ -130,7 +130,9 @@ SIGNATURES = {
     "jpegx_comm_available": [],
     "jpegx_comm_unique_id": [_vp],
     "jpegx_comm_create": [_c.POINTER(_vp), _int, _int, _vp],
+    "jpegx_comm_create_deadline": [_c.POINTER(_vp), _int, _int, _vp, _dbl],
     "jpegx_comm_destroy": [_vp],
+    "jpegx_comm_abort": [_vp],
     "jpegx_comm_count": [_vp, _c.POINTER(_int)],
     "jpegx_comm_gather_bytes": [_vp, _vp, _sz, _vp, _c.POINTER(_sz), _c.POINTER(_sz), _int, _vp],
 }

@@ -71,18 +71,68 @@ def _free_port():
         return s.getsockname()[1]
 
 
+def rank_process_env(env=None):
+    """Environment every rank process needs BEFORE anything loads HIP / RCCL, whoever launched it (set with
+    setdefault: an explicit choice of the caller wins).
+
+    * ``HSA_ENABLE_IPC_MODE_LEGACY=0``: the host driver only supports dmabuf IPC; without it RCCL's peer-to-peer
+      setup fails in hipIpcGetMemHandle.
+    * ``RSMI_MUTEX_THREAD_ONLY=1``: RCCL's communicator creation queries rocm_smi, which serialises its device
+      queries through a PROCESS-SHARED pthread mutex kept in ``/dev/shm/rocm_smi_*``.  A process that ended
+      uncleanly while holding it (seen after rocprofv3 passes on the same box, round 2) leaves it locked: the next
+      rsmi_init times out on it after 5 s ("init_mutex ... unlock timed lock, ret: 1") and the blocking lock of the
+      first device query behind it never returns -- both ranks "sat in communicator creation".  With this variable
+      rocm_smi uses a process-local mutex instead, which is all one-process-per-GPU ranks need (they only read sysfs).
+    * ``JPEGX_COMM_LOG=1``: libjpegx logs the phases of the RCCL calls to stderr with time stamps.
+    """
+    env = os.environ if env is None else env
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("RSMI_MUTEX_THREAD_ONLY", "1")
+    env.setdefault("JPEGX_COMM_LOG", "1")
+    return env
+
+
+def rsmi_shm_report(shm_dir="/dev/shm"):
+    """State of rocm_smi's process-shared mutexes (``/dev/shm/rocm_smi_*``, a pthread_mutex_t at offset 0): for each
+    file the lock word, the owner's thread id and whether that thread still exists.  ``stale`` = locked by a thread
+    that is gone: the condition behind round 2's hang in communicator creation (see rank_process_env)."""
+    out = []
+    try:
+        names = sorted(n for n in os.listdir(shm_dir) if n.startswith("rocm_smi"))
+    except OSError:
+        return out
+    for n in names:
+        rec = {"file": n}
+        try:
+            with open(os.path.join(shm_dir, n), "rb") as f:
+                head = f.read(16)
+            if len(head) >= 12:
+                lock, _count, owner = struct.unpack("<IIi", head[:12])
+                rec.update(lock=lock, owner_tid=owner)
+                tid = owner if owner > 0 else (lock & 0x3FFFFFFF)
+                alive = bool(tid) and os.path.exists("/proc/%d" % tid)
+                rec["owner_alive"] = alive
+                rec["stale"] = bool(lock != 0 and tid and not alive)
+        except OSError as exc:
+            rec["error"] = "%s: %s" % (type(exc).__name__, exc)
+        out.append(rec)
+    return out
+
+
 def launch_ranks(nranks, argv, extra_env=None, poll_s=0.05, grace_s=10.0):
     """Run ``python argv...`` once per rank and return the job's exit code (0 iff every rank
     returned 0).  Must be called before the calling process has touched the GPU.  When a rank
     fails the others are given ``grace_s`` seconds and are then terminated by PID."""
     port = _free_port()
+    token = base64.b16encode(os.urandom(16)).decode()      # what a rank must present to join this job's control plane
     procs = []
     for r in range(nranks):
         env = dict(os.environ)
+        env["JPEGX_CTL_TOKEN"] = token
         env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(nranks),
                     "LOCAL_WORLD_SIZE": str(nranks), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port),
                     "JPEGX_LAUNCHER": "jpegx.multigpu.launch_ranks"})
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL peer-to-peer needs it here
+        rank_process_env(env)
         if extra_env:
             env.update(extra_env)
         procs.append(subprocess.Popen([sys.executable] + list(argv), env=env))
@@ -148,12 +198,32 @@ class ControlPlane:
         if key is None:
             key = "%s_%s" % (os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "none"))
         self.key = "".join(c if c.isalnum() or c in "._-" else "_" for c in str(key))
-        base = os.environ.get("JPEGX_CTL_DIR") or "/tmp"
-        self._path = os.path.join(base, "jpegx_ctl_%d_%s" % (os.getuid(), self.key))
+        self._token = os.environ.get("JPEGX_CTL_TOKEN") or None     # launch_ranks hands one over; else rank 0 makes one
+        self._path = os.path.join(self._rendezvous_dir(), "jpegx_ctl_%d_%s" % (os.getuid(), self.key))
         if self.rank == 0:
             self._serve(connect_timeout)
         else:
             self._join(connect_timeout)
+
+    @staticmethod
+    def _rendezvous_dir():
+        """A directory only this user can write to: JPEGX_CTL_DIR if given, else XDG_RUNTIME_DIR, else a 0700
+        directory of our own under /tmp (never /tmp itself: there another user could plant the file or a symlink)."""
+        base = os.environ.get("JPEGX_CTL_DIR") or os.environ.get("XDG_RUNTIME_DIR")
+        if base and os.path.isdir(base):
+            st = os.stat(base)
+            if st.st_uid == os.getuid() and os.access(base, os.W_OK):
+                return base
+        own = os.path.join("/tmp", "jpegx_ctl_%d.d" % os.getuid())
+        try:
+            os.mkdir(own, 0o700)
+        except FileExistsError:
+            pass
+        st = os.lstat(own)
+        import stat as _stat
+        if not _stat.S_ISDIR(st.st_mode) or st.st_uid != os.getuid() or (st.st_mode & 0o077):
+            raise ControlPlaneError("%s exists but is not a private directory of uid %d" % (own, os.getuid()))
+        return own
 
     # -- wire format: 4-byte big-endian length + UTF-8 JSON -----------------------------------
     @staticmethod
@@ -180,9 +250,18 @@ class ControlPlane:
         srv.bind(("127.0.0.1", 0))
         srv.listen(self.world)
         port = srv.getsockname()[1]
+        if self._token is None:
+            self._token = base64.b16encode(os.urandom(16)).decode()
         tmp = "%s.%d.tmp" % (self._path, os.getpid())
-        with open(tmp, "w") as f:
-            f.write("%d %d\n" % (port, os.getpid()))
+        try:
+            os.unlink(tmp)
+        except OSError:
+            pass
+        # O_EXCL | O_NOFOLLOW: never write through something another process put there; 0600: the token in it is
+        # what a joining rank must echo, so only this user's processes can join
+        fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL | getattr(os, "O_NOFOLLOW", 0), 0o600)
+        with os.fdopen(fd, "w") as f:
+            f.write("%d %d %s\n" % (port, os.getpid(), self._token))
         os.replace(tmp, self._path)                        # atomic publish (replaces a stale file)
         deadline = time.monotonic() + connect_timeout
         try:
@@ -200,6 +279,7 @@ class ControlPlane:
                     conn.close()
                     continue
                 ok = (isinstance(hello, dict) and hello.get("magic") == self.MAGIC and hello.get("key") == self.key
+                      and hello.get("token") == self._token
                       and hello.get("world") == self.world and isinstance(hello.get("rank"), int)
                       and 0 < hello["rank"] < self.world and hello["rank"] not in self._peers)
                 self._send(conn, {"ok": bool(ok)})
@@ -218,11 +298,15 @@ class ControlPlane:
         while time.monotonic() < deadline:
             try:
                 with open(self._path) as f:
-                    port = int(f.read().split()[0])
+                    fields = f.read().split()
+                port = int(fields[0])
+                token = fields[2] if len(fields) > 2 else ""
+                if self._token is not None and token != self._token:
+                    raise ValueError("rendezvous file of another job (token mismatch)")
                 s = socket.create_connection(("127.0.0.1", port), timeout=5.0)
                 try:
                     s.settimeout(10.0)
-                    self._send(s, {"magic": self.MAGIC, "key": self.key, "world": self.world, "rank": self.rank})
+                    self._send(s, {"magic": self.MAGIC, "key": self.key, "world": self.world, "rank": self.rank, "token": token})
                     if self._recv(s).get("ok"):
                         s.settimeout(self.timeout)
                         s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
@@ -302,19 +386,42 @@ class NativeComm:
     every rank -- ``ControlPlane.bcast_bytes`` here; an MPI bcast or a shared file would do too.
     """
 
-    def __init__(self, nranks, rank, exchange_id):
+    @staticmethod
+    def unique_id():
+        """ncclGetUniqueId through libjpegx: the 128 bytes rank 0 hands to every rank."""
+        import ctypes
+        import jpegx
+        buf = ctypes.create_string_buffer(128)
+        jpegx.check(jpegx.lib().jpegx_comm_unique_id(buf), "jpegx_comm_unique_id")
+        return buf.raw
+
+    def __init__(self, nranks, rank, exchange_id=None, timeout_s=0.0, ident=None):
+        """``timeout_s``: deadline of communicator creation and of every later enqueue wait (0: JPEGX_COMM_TIMEOUT_S
+        from the environment, else 120 s); a JpegxError carrying libjpegx's JPEGX_E_TIMEOUT text when it runs out.
+        ``ident``: the 128-byte id when the caller has already distributed it (then ``exchange_id`` is not used)."""
         import ctypes
         import jpegx
         self._jpegx = jpegx
         L = jpegx.lib()
-        ident = None
-        if rank == 0:
-            buf = ctypes.create_string_buffer(128)
-            jpegx.check(L.jpegx_comm_unique_id(buf), "jpegx_comm_unique_id")
-            ident = buf.raw
-        ident = exchange_id(ident)
+        t0 = time.monotonic()
+        log = os.environ.get("JPEGX_COMM_LOG", "0") not in ("", "0")
+
+        def say(what):
+            if log:
+                sys.stderr.write("[jpegx comm rank %d/%d pid %d +%.3fs] %s\n" % (rank, nranks, os.getpid(), time.monotonic() - t0, what))
+                sys.stderr.flush()
+        if ident is None:
+            if rank == 0:
+                ident = self.unique_id()
+            say("id-broadcast enter")
+            ident = exchange_id(ident)
+            say("id-broadcast done")
+        stale = [r for r in rsmi_shm_report() if r.get("stale")]
+        if stale:
+            say("WARNING stale rocm_smi shared mutex (locked by a thread that is gone): %s; RSMI_MUTEX_THREAD_ONLY=%s"
+                % (json.dumps(stale), os.environ.get("RSMI_MUTEX_THREAD_ONLY", "unset")))
         handle = ctypes.c_void_p()
-        jpegx.check(L.jpegx_comm_create(ctypes.byref(handle), nranks, rank, ident), "jpegx_comm_create")
+        jpegx.check(L.jpegx_comm_create_deadline(ctypes.byref(handle), nranks, rank, ident, float(timeout_s)), "jpegx_comm_create")
         self.handle, self.nranks, self.rank = handle.value, nranks, rank
 
     def count(self):
@@ -344,6 +451,12 @@ class NativeComm:
     def close(self):
         if self.handle:
             self._jpegx.lib().jpegx_comm_destroy(self.handle)
+            self.handle = None
+
+    def abort(self):
+        """ncclCommAbort: drop outstanding operations (after a failed or timed-out round) and free the handle."""
+        if self.handle:
+            self._jpegx.lib().jpegx_comm_abort(self.handle)
             self.handle = None
 
 

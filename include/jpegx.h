@@ -40,6 +40,7 @@ extern "C" {
 #define JPEGX_E_HIP (-2)      /* a HIP runtime call failed; message has hipGetErrorString */
 #define JPEGX_E_NODEVICE (-3) /* no usable GPU */
 #define JPEGX_E_UNSUPPORTED (-4)
+#define JPEGX_E_TIMEOUT (-5)  /* a wait with a deadline ran out (RCCL communicator creation / first exchange) */
 
 /* Quantiser selection: pipeline/__init__.py:13-19 (QuantizationMethod.name_to_quantizer). */
 typedef enum jpegx_quant_mode {
@@ -253,12 +254,19 @@ int jpegx_host_entropy_decode(const uint8_t *h_bytes, size_t nbytes, long long n
  *   rank 0: jpegx_comm_unique_id -> ship the 128 bytes to every rank (any side channel) ->
  *   all ranks: jpegx_comm_create(nranks, rank, id) on the thread's current device ->
  *   jpegx_comm_gather_bytes(...): every rank sends send_bytes; the root receives recv_bytes[r] bytes
- *   from rank r at d_recv + recv_offsets[r].  Enqueued on `stream`.                              */
+ *   from rank r at d_recv + recv_offsets[r].  Enqueued on `stream`.
+ * No call blocks without a deadline: the communicator is created non-blocking (ncclCommInitRankConfig,
+ * blocking = 0) and polled; when `timeout_s` (jpegx_comm_create: JPEGX_COMM_TIMEOUT_S from the
+ * environment, else 120 s) runs out in creation or in a gather round's enqueue (the first round sets up the
+ * peer connections) the call returns JPEGX_E_TIMEOUT with the phase in jpegx_last_error().  JPEGX_COMM_LOG=1
+ * in the environment logs init-enter / init-exit / first-round lines with time stamps to stderr.          */
 typedef void *jpegx_comm_t;
 int jpegx_comm_available(void); /* 0 iff librccl could be bound (no communicator is created) */
 int jpegx_comm_unique_id(void *id128);
 int jpegx_comm_create(jpegx_comm_t *comm, int nranks, int rank, const void *id128);
+int jpegx_comm_create_deadline(jpegx_comm_t *comm, int nranks, int rank, const void *id128, double timeout_s);
 int jpegx_comm_destroy(jpegx_comm_t comm);
+int jpegx_comm_abort(jpegx_comm_t comm);  /* ncclCommAbort: give up outstanding operations, free the handle */
 int jpegx_comm_count(jpegx_comm_t comm, int *nranks); /* ncclCommCount: the size RCCL reports */
 int jpegx_comm_gather_bytes(jpegx_comm_t comm, const void *d_send, size_t send_bytes, void *d_recv,
                             const size_t *recv_bytes, const size_t *recv_offsets, int root,

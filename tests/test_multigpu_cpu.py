@@ -218,8 +218,78 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _bench_line(res):
-    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+def test_rank_environment_is_set_before_anything_loads_hip(tmp_path):
+    """What a rank needs in its environment whoever launched it: dmabuf IPC for RCCL, rocm_smi's mutex process-local
+    (the cause of round 2's hang in communicator creation), phase logging; an explicit choice of the caller wins."""
+    from jpegx.multigpu import rank_process_env
+    env = rank_process_env({})
+    assert env == {"HSA_ENABLE_IPC_MODE_LEGACY": "0", "RSMI_MUTEX_THREAD_ONLY": "1", "JPEGX_COMM_LOG": "1"}
+    assert rank_process_env({"RSMI_MUTEX_THREAD_ONLY": "0"})["RSMI_MUTEX_THREAD_ONLY"] == "0"
+    # bench.py as a rank of an external launcher sets it itself, before importing jpegx
+    probe = tmp_path / "probe.py"
+    probe.write_text("import os, sys, runpy\nsys.argv = [%r, '--gpus', '1', '--dry-run']\n"
+                     "os.environ.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')\n"
+                     "for k in ('HSA_ENABLE_IPC_MODE_LEGACY', 'RSMI_MUTEX_THREAD_ONLY'): os.environ.pop(k, None)\n"
+                     "try:\n    runpy.run_path(%r, run_name='__main__')\nexcept SystemExit:\n    pass\n"
+                     "print('ENV', os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY'), os.environ.get('RSMI_MUTEX_THREAD_ONLY'))\n"
+                     % (os.path.join(REPO, "bench.py"), os.path.join(REPO, "bench.py")))
+    res = subprocess.run([sys.executable, str(probe)], capture_output=True, text=True, timeout=300)
+    assert "ENV 0 1" in res.stdout + res.stderr, res.stdout[-1000:] + res.stderr[-1000:]   # bench.py points fd 1 at stderr
+
+
+def test_rsmi_shm_report_flags_a_mutex_left_locked_by_a_dead_thread(tmp_path):
+    """The detector behind the warning printed before communicator creation: a pthread_mutex_t image whose lock word
+    is set and whose owner thread does not exist is stale; an unlocked one and one held by a live thread are not."""
+    import struct
+    from jpegx.multigpu import rsmi_shm_report
+    dead = 0x3FFFFF00                                        # no such thread
+    (tmp_path / "rocm_smi_renderD1").write_bytes(struct.pack("<IIi", 1, 1, dead) + bytes(28))
+    (tmp_path / "rocm_smi_renderD2").write_bytes(bytes(40))
+    (tmp_path / "rocm_smi_renderD3").write_bytes(struct.pack("<IIi", 1, 1, os.getpid()) + bytes(28))
+    (tmp_path / "unrelated").write_bytes(b"x")
+    rep = {r["file"]: r for r in rsmi_shm_report(str(tmp_path))}
+    assert sorted(rep) == ["rocm_smi_renderD1", "rocm_smi_renderD2", "rocm_smi_renderD3"]
+    assert rep["rocm_smi_renderD1"]["stale"] and not rep["rocm_smi_renderD2"]["stale"] and not rep["rocm_smi_renderD3"]["stale"]
+    assert rsmi_shm_report(str(tmp_path / "missing")) == []
+
+
+INTRUDER_WORKER = r'''
+import os, sys, socket, json, struct, time
+sys.path.insert(0, %(pkg)r)
+from jpegx.multigpu import ControlPlane, rank_env
+rank, local_rank, world = rank_env()
+if rank == 1:
+    # before joining properly, play a foreign process that knows port, magic, key and world but not the token
+    path = os.path.join(os.environ["JPEGX_CTL_DIR"], "jpegx_ctl_%%d_%%s_none" %% (os.getuid(), os.environ["MASTER_PORT"]))
+    for _ in range(400):
+        if os.path.exists(path):
+            break
+        time.sleep(0.05)
+    port = int(open(path).read().split()[0])
+    mode = os.stat(path).st_mode & 0o777
+    s = socket.create_connection(("127.0.0.1", port), timeout=5)
+    msg = json.dumps({"magic": ControlPlane.MAGIC, "key": "%%s_none" %% os.environ["MASTER_PORT"], "world": world, "rank": 1, "token": "guess"}).encode()
+    s.sendall(struct.pack(">I", len(msg)) + msg)
+    n = struct.unpack(">I", s.recv(4))[0]
+    refused = json.loads(s.recv(n).decode()) == {"ok": False}
+    s.close()
+    if not refused or mode != 0o600:
+        os._exit(9)
+with ControlPlane() as ctl:
+    assert ctl.allgather(rank) == list(range(world))
+'''
+
+
+def test_control_plane_refuses_a_hello_without_the_job_token(tmp_path):
+    """The rendezvous file is private (0600, created with O_EXCL | O_NOFOLLOW) and carries a random token that a
+    joining process must echo: knowing port, magic, key and world is not enough to impersonate a rank."""
+    from jpegx.multigpu import launch_ranks
+    script = _write(tmp_path, "intruder_worker.py", INTRUDER_WORKER)
+    assert launch_ranks(2, [script], extra_env={"JPEGX_CTL_DIR": str(tmp_path)}) == 0
+
+
+def _bench_line(res, returncode=0):
+    assert res.returncode == returncode, res.stdout[-2000:] + res.stderr[-2000:]
     lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, res.stdout
     return json.loads(lines[0])
@@ -263,8 +333,9 @@ def test_bench_runs_as_ranks_of_torch_distributed_run(tmp_path):
 @pytest.mark.parametrize("launcher", ["own", "torch"])
 def test_watchdog_of_the_gather_legs_keeps_the_result_line(tmp_path, launcher):
     """An exchange that never comes back (rehearsed with --dry-run-stall): rank 0 still prints its line, with the
-    timeout recorded under "gather", every rank leaves with status 0 and the job as a whole reports success --
-    under the own launcher and as ranks of torch.distributed.run."""
+    timeout recorded under "gather", and then every rank leaves with a NON-ZERO status, so that the job as a whole
+    reports the failed exchange -- under the own launcher (which passes the ranks' status on) and as ranks of
+    torch.distributed.run (which answers a failed rank with status 1)."""
     env = dict(os.environ, JPEGX_CTL_DIR=str(tmp_path), OMP_NUM_THREADS="1")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
         env.pop(k, None)
@@ -276,8 +347,7 @@ def test_watchdog_of_the_gather_legs_keeps_the_result_line(tmp_path, launcher):
                "--master-port", str(_free_port())] + tail
     t0 = time.time()
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
-    line = _bench_line(res)
-    assert res.returncode == 0
+    line = _bench_line(res, returncode=3 if launcher == "own" else 1)
     assert line["dry_run"] and line["n_gpus"] == 2 and "did not finish within 1 s" in line["gather"]["error"]
     assert time.time() - t0 < 100          # nobody sat out the 120 s stall
 
