@@ -961,8 +961,13 @@ __global__ __launch_bounds__(64) void k_forward_fused_f64in(const double *__rest
 // LDS-DMA of the wave's rows, lane-per-block compute, exact tier fed from LDS, tile write-out.
 // BS=1 needs W % 16 == 0 (a 16-byte DMA chunk holds the rows of two adjacent blocks).
 // ------------------------------------------------------------------------------------------------
+#ifdef JPEGX_U8_WPE   // A/B builds only (microbench/build_variant.sh): pin the register budget to N waves per SIMD
+#define JPEGX_U8_OCC __attribute__((amdgpu_waves_per_eu(JPEGX_U8_WPE, JPEGX_U8_WPE)))
+#else
+#define JPEGX_U8_OCC
+#endif
 template <bool DC_EXACT, int BS, bool NT>
-__global__ __launch_bounds__(64) void k_forward_fused_u8(const unsigned char *__restrict__ in, size_t pitch, int wb,
+__global__ __launch_bounds__(64) JPEGX_U8_OCC void k_forward_fused_u8(const unsigned char *__restrict__ in, size_t pitch, int wb,
                                                          int nblk, QuantParams prm, int16_t *__restrict__ out,
                                                          unsigned long long *counters)
 {

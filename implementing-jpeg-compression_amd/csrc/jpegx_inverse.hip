@@ -196,8 +196,13 @@ __device__ __forceinline__ void store_row(void *base, size_t opitch, int r, cons
 // fused inverse: un-zigzag + dequantise + IDCT + round (+ clamp).  OUT: 0 f32, 1 i16, 2 u8.
 // ------------------------------------------------------------------------------------------------
 // INF: SubSampling.invert replication factor fused into the uint8 write-out (1 for the other types).
+#ifdef JPEGX_INV_WPE   // A/B builds only (microbench/build_variant.sh)
+#define JPEGX_INV_OCC __attribute__((amdgpu_waves_per_eu(JPEGX_INV_WPE, JPEGX_INV_WPE)))
+#else
+#define JPEGX_INV_OCC
+#endif
 template <int OUT, bool NT, int INF>
-__global__ __launch_bounds__(64) void k_inverse_fused(const int16_t *__restrict__ in, int wb, int nblk,
+__global__ __launch_bounds__(64) JPEGX_INV_OCC void k_inverse_fused(const int16_t *__restrict__ in, int wb, int nblk,
                                                       QuantParams prm, int clamp,
                                                       void *__restrict__ outv, size_t opitch,
                                                       unsigned long long *counters)

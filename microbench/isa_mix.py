@@ -5,7 +5,7 @@ txt = open(sys.argv[1]).read()
 flt = sys.argv[2] if len(sys.argv) > 2 else ""
 starts = [(m.start(), m.group(1)) for m in re.finditer(r"^(_Z\S+):\s", txt, flags=re.M)]
 for (pos, name), nxt in zip(starts, starts[1:] + [(len(txt), None)]):
-    body = txt[pos:nxt[0]].split(".end_amdhsa_kernel")[0].split("s_endpgm")[0]
+    body = txt[pos:nxt[0]].split(".amdhsa_kernel")[0].split(".end_amdhsa_kernel")[0]      # kernels with an early exit hold several s_endpgm
     dem = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip()
     dem = re.sub(r"\(anonymous namespace\)::|\(.*$|^void ", "", dem)
     if flt not in dem:

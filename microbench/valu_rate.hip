@@ -1,0 +1,124 @@
+// Issue rate of the fp32 / integer VALU instructions the fused forward and inverse kernels are made of, on one
+// MI355X: wave-level instructions per second per SIMD, 8 independent chains per lane, at 1 / 2 / 4 / 8 waves per
+// SIMD.  The question behind it: does a hand-packed v_pk_fma_f32 / v_pk_mul_f32 /
+// v_pk_add_f32 butterfly halve the VALU time of the DCT, i.e. does a packed instruction issue at the rate of a
+// plain one (2 results per slot) or at half of it (no gain)?  "flops-equivalent" below counts a packed
+// instruction as two.
+//   hipcc --offload-arch=gfx950 -O3 -o microbench/valu_rate microbench/valu_rate.hip && microbench/valu_rate
+#include <hip/hip_runtime.h>
+#include <cstdio>
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int OP>
+__global__ __launch_bounds__(256) void k_rate(float *out, int iters, float seed)
+{
+    float f[8];
+    f32x2 p[8];
+    unsigned u[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        f[k] = seed + k + threadIdx.x * 1e-3f;
+        p[k] = f32x2{f[k], f[k] + 0.5f};
+        u[k] = (unsigned)threadIdx.x * 2654435761u + k;
+    }
+    const float m = 1.0000001f, c = 1e-9f;
+    const float sm = __builtin_amdgcn_readfirstlane(__float_as_int(seed)) ? 1.0000001f : 1.0f;   // lives in an SGPR
+    const f32x2 pm = {m, m}, pc = {c, c};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (OP == 0) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(f[k]) : "v"(m), "v"(c));
+                if (OP == 1) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[k]) : "v"(pm), "v"(pc));
+                if (OP == 2) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p[k]) : "v"(pm));
+                if (OP == 3) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[k]) : "v"(pc));
+                if (OP == 4) asm volatile("v_add_f32 %0, %0, %1" : "+v"(f[k]) : "v"(c));
+                if (OP == 5) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(f[k]) : "v"(m));
+                if (OP == 6) asm volatile("v_rndne_f32 %0, %0" : "+v"(f[k]));
+                if (OP == 7) asm volatile("v_cvt_i32_f32 %0, %1" : "=v"(u[k]) : "v"(f[k]));
+                if (OP == 8) asm volatile("v_cvt_f32_ubyte1 %0, %1" : "=v"(f[k]) : "v"(u[k]));
+                if (OP == 9) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(u[k]) : "v"(u[(k + 1) & 7]), "v"(0x05040100u));
+                if (OP == 10) asm volatile("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(f[k]) : "v"(m), "v"(c));
+                if (OP == 11) asm volatile("v_fma_f32 %0, %1, |%2|, |%0|" : "+v"(f[k]) : "v"(m), "v"(c));
+                if (OP == 12) asm volatile("v_med3_f32 %0, %0, %1, %2" : "+v"(f[k]) : "v"(c), "v"(m));
+                if (OP == 13) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(u[k]) : "v"(0xFFFFu), "v"(u[(k + 1) & 7]));
+                if (OP == 14) asm volatile("v_lshl_or_b32 %0, %0, 16, %1" : "+v"(u[k]) : "v"(u[(k + 1) & 7]));
+                if (OP == 15) asm volatile("v_cvt_pk_i16_i32 %0, %0, %1" : "+v"(u[k]) : "v"(u[(k + 1) & 7]));
+                if (OP == 16) asm volatile("v_cvt_pk_u8_f32 %0, %1, 1, %0" : "+v"(u[k]) : "v"(f[k]));
+                if (OP == 17) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(f[k]) : "v"(c));
+                if (OP == 18) asm volatile("v_pk_add_f32 %0, %0, %1 neg_lo:[0,1] neg_hi:[0,0]" : "+v"(p[k]) : "v"(pc));
+                if (OP == 19) asm volatile("v_pk_fma_f32 %0, %0, %1, %2 op_sel:[0,1,0] op_sel_hi:[1,0,1]" : "+v"(p[k]) : "v"(pm), "v"(pc));
+                if (OP == 20) asm volatile("v_bfe_u32 %0, %1, 8, 8" : "=v"(u[k]) : "v"(u[(k + 1) & 7]));
+                if (OP == 21) asm volatile("v_mov_b32 %0, %1" : "=v"(u[k]) : "v"(u[(k + 1) & 7]));
+                if (OP == 22) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(f[k]) : "s"(sm), "v"(c));            // one SGPR operand
+                if (OP == 23) asm volatile("v_fmamk_f32 %0, %0, 0x3f7b14be, %1" : "+v"(f[k]) : "v"(c));          // VOP2 + 32-bit literal
+                if (OP == 24) asm volatile("v_mul_f32 %0, %1, %0" : "+v"(f[k]) : "s"(sm));                        // VOP2 with an SGPR
+                if (OP == 25) asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(f[k]) : "v"(f[(k + 1) & 7]), "v"(f[(k + 2) & 7]), "v"(f[(k + 3) & 7]));
+                if (OP == 26) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(f[0]) : "v"(m), "v"(c));            // ONE dependent chain
+                if (OP == 27) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(f[k & 1]) : "v"(m), "v"(c));        // two chains
+                if (OP == 28) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(f[k & 3]) : "v"(m), "v"(c));        // four chains
+                if (OP == 29) asm volatile("v_cvt_f32_i32 %0, %1" : "=v"(f[k]) : "v"(u[k]));
+                if (OP == 30) asm volatile("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(f[k]) : "v"(u[k]));
+                if (OP == 31) asm volatile("v_cvt_u32_f32 %0, %1" : "=v"(u[k]) : "v"(f[k]));
+            }
+        }
+    }
+    float s = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += f[k] + p[k].x + p[k].y + (float)u[k];
+    if (s == 12345.678f) out[0] = s;
+}
+
+static const char *NAMES[] = {"v_fma_f32", "v_pk_fma_f32", "v_pk_mul_f32", "v_pk_add_f32", "v_add_f32", "v_mul_f32", "v_rndne_f32",
+                              "v_cvt_i32_f32", "v_cvt_f32_ubyte1", "v_perm_b32", "v_max3_f32 |a| |b|", "v_fma_f32 a |b| |c|", "v_med3_f32",
+                              "v_and_or_b32", "v_lshl_or_b32", "v_cvt_pk_i16_i32", "v_cvt_pk_u8_f32", "v_sub_f32", "v_pk_add_f32 neg_lo",
+                              "v_pk_fma_f32 op_sel", "v_bfe_u32", "v_mov_b32", "v_fma_f32 (sgpr src)", "v_fmamk_f32 (literal)", "v_mul_f32 (sgpr src)",
+                              "v_fma_f32 3 vgpr srcs", "v_fma_f32 1 chain", "v_fma_f32 2 chains", "v_fma_f32 4 chains", "v_cvt_f32_i32",
+                              "v_cvt_f32_i32 sdwa", "v_cvt_u32_f32"};
+
+static double g_base = 0;
+
+template <int OP>
+void run(float *d, int waves_per_simd = 8)
+{
+    const int iters = 4096, grid = 256 * waves_per_simd;            // workgroups of 4 waves, one wave per SIMD each
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL((k_rate<OP>), dim3(grid), dim3(256), 0, 0, d, 64, 1.0f);
+    hipDeviceSynchronize();
+    float best = 1e30f;
+    for (int rep = 0; rep < 3; ++rep) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL((k_rate<OP>), dim3(grid), dim3(256), 0, 0, d, iters, 1.0f);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms = 0;
+        hipEventElapsedTime(&ms, e0, e1);
+        if (ms < best) best = ms;
+    }
+    const double wave_instr = (double)grid * 4 * iters * 32;           // wave-level instructions issued
+    const double per_simd_per_s = wave_instr / (best * 1e-3) / (256 * 4);
+    if (OP == 0 && waves_per_simd == 8) g_base = per_simd_per_s;
+    printf("%-22s %d waves/SIMD %8.3f ms  %6.3f G wave-instr/s per SIMD  x%.2f of v_fma_f32 @8\n", NAMES[OP], waves_per_simd, best,
+           per_simd_per_s * 1e-9, g_base > 0 ? per_simd_per_s / g_base : 0.0);
+}
+
+template <int OP> void sweep(float *d) { run<OP>(d, 8); }
+
+int main()
+{
+    float *d;
+    hipMalloc(&d, 64);
+    run<0>(d, 8);
+    sweep<1>(d); sweep<2>(d); sweep<3>(d); sweep<18>(d); sweep<19>(d);
+    sweep<4>(d); sweep<5>(d); sweep<17>(d); sweep<6>(d); sweep<7>(d); sweep<8>(d); sweep<9>(d); sweep<10>(d); sweep<11>(d); sweep<12>(d);
+    sweep<13>(d); sweep<14>(d); sweep<15>(d); sweep<16>(d); sweep<20>(d); sweep<21>(d);
+    sweep<22>(d); sweep<23>(d); sweep<24>(d); sweep<25>(d); sweep<26>(d); sweep<27>(d); sweep<28>(d); sweep<29>(d); sweep<30>(d); sweep<31>(d);
+    for (int w : {1, 2, 4}) run<26>(d, w);
+    for (int w : {1, 2, 4}) run<28>(d, w);
+    for (int w : {1, 2, 3, 4, 6}) run<0>(d, w);
+    for (int w : {1, 2, 4}) run<1>(d, w);
+    return 0;
+}
