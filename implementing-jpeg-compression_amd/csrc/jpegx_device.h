@@ -209,8 +209,20 @@ __device__ __forceinline__ double coop_inv_exact(double z_own, double *sA, doubl
 // Quantise the 64 coefficients of v (natural order) in zigzag order and pack them as int16 pairs
 // (pipeline/quantization.py:8-18 + pipeline/zigzag_order.py:85-99; the zigzag is a compile-time
 // renaming).  E = u S (jpegx_fwd_err_unit); a coefficient's bound is E F(k, l) / q with F = jpegx_fwd_roundings.
-// Returns the worst rounding margin max(|t - rint(t)| + E F / q): the block is safe iff it stays below 1/2.
+// Returns the worst rounding margin max(|t - rint(t)| + E F / q): the block is safe iff it stays below JPEGX_SAFE_HALF.
+// Round 3: jpegx_quant_fast (magic-constant rounding of the exact product, jpegx_math.h) and one byte permute per pair.
 // PIXEL: values provably fit int16, no saturation needed; the row pass's butterfly adds are exact.
+// int16 pair from two magic-biased quantiser outputs (jpegx_quant_fast): the low halves of their bit patterns
+__device__ __forceinline__ unsigned pack_magic_pair(float m0, float m1)
+{
+    return __builtin_amdgcn_perm(__float_as_uint(m1), __float_as_uint(m0), 0x05040100u);
+}
+// saturation of a magic-biased value to the int16 range (generic input only; one v_med3)
+__device__ __forceinline__ float clamp_magic_i16(float m)
+{
+    return __builtin_amdgcn_fmed3f(m, JPEGX_RMAGIC - 32768.0f, JPEGX_RMAGIC + 32767.0f);
+}
+
 template <bool PIXEL, bool DC_EXACT>
 __device__ __forceinline__ float quantise_zigzag_pack(const float (&v)[64], const QuantParams &prm, float E,
                                                       unsigned (&pk)[32])
@@ -219,24 +231,21 @@ __device__ __forceinline__ float quantise_zigzag_pack(const float (&v)[64], cons
     float Ef[15];                       // E = u S (jpegx_fwd_err_unit) times the coefficient's rounding count F(k, l)
 #pragma unroll
     for (int j = 0; j < 15; ++j) Ef[j] = E * (float)j;
+    float magic = JPEGX_RMAGIC;
+    asm volatile("" : "+v"(magic));     // one live register, see jpegx_quant_fast_m
 #pragma unroll
     for (int p = 0; p < 64; p += 2) {
-        int q[2];
+        float m[2];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int n = kZZ.v[p + h];
             const float rq = prm.rq32[n];
-            const float t = v[n] * rq;
-            const float r = rintf(t);
-            if (!(DC_EXACT && n == 0)) worst = fmaxf(worst, fmaf(Ef[jpegx_fwd_roundings(n, PIXEL)], fabsf(rq), fabsf(t - r)));
-            q[h] = (int)r;
+            float d;
+            m[h] = jpegx_quant_fast_m(v[n], rq, magic, d);
+            if (!(DC_EXACT && n == 0)) worst = fmaxf(worst, fmaf(Ef[jpegx_fwd_roundings(n, PIXEL)], fabsf(rq), fabsf(d)));
+            if (!PIXEL) m[h] = clamp_magic_i16(m[h]);
         }
-        if (PIXEL) {
-            pk[p >> 1] = ((unsigned)q[0] & 0xFFFFu) | ((unsigned)q[1] << 16);
-        } else {
-            const int a = min(max(q[0], -32768), 32767), b = min(max(q[1], -32768), 32767);
-            pk[p >> 1] = ((unsigned)a & 0xFFFFu) | ((unsigned)b << 16);
-        }
+        pk[p >> 1] = pack_magic_pair(m[0], m[1]);
     }
     return worst;
 }
@@ -252,28 +261,25 @@ __device__ __forceinline__ unsigned quantise_zigzag_pack_cols(const float (&v)[6
     float Ef[15];
 #pragma unroll
     for (int j = 0; j < 15; ++j) Ef[j] = E * (float)j;
+    float magic = JPEGX_RMAGIC;
+    asm volatile("" : "+v"(magic));
 #pragma unroll
     for (int p = 0; p < 64; p += 2) {
-        int q[2];
+        float m[2];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int n = kZZ.v[p + h];
             const float rq = prm.rq32[n];
-            const float t = v[n] * rq;
-            const float r = rintf(t);
-            if (!(DC_EXACT && n == 0)) worst[n & 7] = fmaxf(worst[n & 7], fmaf(Ef[jpegx_fwd_roundings(n, PIXEL)], fabsf(rq), fabsf(t - r)));
-            q[h] = (int)r;
+            float d;
+            m[h] = jpegx_quant_fast_m(v[n], rq, magic, d);
+            if (!(DC_EXACT && n == 0)) worst[n & 7] = fmaxf(worst[n & 7], fmaf(Ef[jpegx_fwd_roundings(n, PIXEL)], fabsf(rq), fabsf(d)));
+            if (!PIXEL) m[h] = clamp_magic_i16(m[h]);
         }
-        if (PIXEL) {
-            pk[p >> 1] = ((unsigned)q[0] & 0xFFFFu) | ((unsigned)q[1] << 16);
-        } else {
-            const int a = min(max(q[0], -32768), 32767), b = min(max(q[1], -32768), 32767);
-            pk[p >> 1] = ((unsigned)a & 0xFFFFu) | ((unsigned)b << 16);
-        }
+        pk[p >> 1] = pack_magic_pair(m[0], m[1]);
     }
     unsigned mask = 0;
 #pragma unroll
-    for (int l = 0; l < 8; ++l) mask |= (worst[l] < 0.5f) ? 0u : (1u << l);
+    for (int l = 0; l < 8; ++l) mask |= (worst[l] < JPEGX_SAFE_HALF) ? 0u : (1u << l);
     return mask;
 }
 

@@ -149,8 +149,9 @@ __device__ __forceinline__ unsigned parse_block(const unsigned *__restrict__ wor
         const bool zero = size == 0;
         const bool eob = (w >> 24) == 0;                                    // end marker, then the zero padding
         const unsigned nn = n + (zero ? 15u : run);                         // a chain code is FIFTEEN zeros (util.py:134-154)
-        // not a block: the stream ends inside the code, a zero size with a run other than 0 / 15, a 65th coefficient
-        const bool bad = (pos + 8 + size > end) | (zero & (run != 15u) & !eob) | (!eob & (nn > (zero ? 64u : 63u)));
+        // not a block: the stream ends inside the code, a zero size with a run other than 0 / 15, a size of 1 (a sign bit
+        // without amplitude bits: the reference's decode_signed fails on it, rle_byte_stream.py:35-42), a 65th coefficient
+        const bool bad = (pos + 8 + size > end) | (zero & (run != 15u) & !eob) | (size == 1u) | (!eob & (nn > (zero ? 64u : 63u)));
         if (WRITE && !zero && !bad) {
             const unsigned bits = (w << 8) >> (32 - size);
             const unsigned mag = bits & ((1u << (size - 1)) - 1u);
@@ -233,7 +234,11 @@ __global__ __launch_bounds__(64) void k_dec_blocks(const unsigned *__restrict__ 
     __syncthreads();
     if (g < nblk) {
         const unsigned p = start_pos[g];
-        if (p == NIL || parse_block<true>(words, (unsigned long long)nbytes * 8u, p, lds, lane) == NIL) atomicOr(&head[1], 2u);
+        const unsigned e = p == NIL ? NIL : parse_block<true>(words, (unsigned long long)nbytes * 8u, p, lds, lane);
+        if (e == NIL) atomicOr(&head[1], 2u);
+        // the last block must end where the stream ends: bytes (or whole blocks) behind it make the reference fail
+        // in its reshape (run_length_encoding.py:77-79), so they are refused here too
+        else if (g == nblk - 1 && e != (unsigned)nbytes) atomicOr(&head[1], 4u);
     }
     __syncthreads();
     unsigned char *dst = reinterpret_cast<unsigned char *>(out) + (size_t)g0 * 128;

@@ -203,7 +203,7 @@ __device__ __forceinline__ void forward_fused_body(unsigned char *lds, int wg, c
             make_uint4(pk[c * 4 + 0], pk[c * 4 + 1], pk[c * 4 + 2], pk[c * 4 + 3]);
 
     // exact tier for blocks that sit within the error bound of a rounding boundary
-    unsigned long long flagged = __ballot(valid && !(worst < 0.5f));
+    unsigned long long flagged = __ballot(valid && !(worst < JPEGX_SAFE_HALF));
     census(counters, flagged, nblk - g0, lane);
     if (prm.tune & 1) flagged = 0;
     __syncthreads();
@@ -282,8 +282,22 @@ __device__ __forceinline__ void forward_fused_body(unsigned char *lds, int wg, c
     store_tile<NT>(lds, out, g0, nblk, lane);
 }
 
+// Register budget (see k_forward_fused_u8 below): the LDS-staged forms hold 10 KiB of LDS (15 waves per CU), so 4
+// waves per SIMD is what the registers should allow; 2 x 2 pooling of pixel input carries its 32-register fp16 stash
+// and would spill at 3 or 4 (A/B: -DJPEGX_POOLED2_WPE=3), so it keeps the scheduler's own choice.
+#ifndef JPEGX_POOLED2_WPE
+#define JPEGX_POOLED2_WPE 2
+#endif
+constexpr int pooled_waves_per_simd(int lds_bytes, bool stash)
+{
+    int w = (163840 / lds_bytes) / 4;             // what the LDS footprint admits per SIMD
+    w = w < 1 ? 1 : (w > 4 ? 4 : w);
+    return (stash && w > JPEGX_POOLED2_WPE) ? JPEGX_POOLED2_WPE : w;
+}
 template <int VAR, int BS, bool NT, int STAGED>
-__global__ __launch_bounds__(64) void k_forward_fused(const float *__restrict__ in, size_t pitch, int wb,
+__global__ __launch_bounds__(64)
+__attribute__((amdgpu_waves_per_eu(STAGED ? pooled_waves_per_simd(PooledLds<BS, STAGED>::BYTES, BS == 2 && (VAR & 1)) : 2)))
+void k_forward_fused(const float *__restrict__ in, size_t pitch, int wb,
                                                       int nblk, QuantParams prm, int16_t *__restrict__ out,
                                                       unsigned long long *counters)
 {
@@ -365,7 +379,7 @@ __device__ __forceinline__ void forward_strip_body(unsigned char *lds, int wg, c
     unsigned pk[32];
     const float worst = quantise_zigzag_pack<PIXEL, DC_EXACT>(v, prm, E, pk);
 
-    unsigned long long flagged = __ballot(valid && !(worst < 0.5f));
+    unsigned long long flagged = __ballot(valid && !(worst < JPEGX_SAFE_HALF));
     census(counters, flagged, nblk - g0, lane);
     if (prm.tune & 1) flagged = 0;
     const double rq_lane = flagged ? c_rq64.v[lane] : 0.0;   // once per wave, not once per flagged block
@@ -961,10 +975,13 @@ __global__ __launch_bounds__(64) void k_forward_fused_f64in(const double *__rest
 // LDS-DMA of the wave's rows, lane-per-block compute, exact tier fed from LDS, tile write-out.
 // BS=1 needs W % 16 == 0 (a 16-byte DMA chunk holds the rows of two adjacent blocks).
 // ------------------------------------------------------------------------------------------------
-#ifdef JPEGX_U8_WPE   // A/B builds only (microbench/build_variant.sh): pin the register budget to N waves per SIMD
+// Register budget: the scheduler trades registers for latency hiding up to what it believes the occupancy
+// allows; told nothing it lets these kernels drift past the 128 / 168 registers of 4 / 3 waves per SIMD and
+// loses a wave.  BS = 1 (9.3 KiB of LDS): 4 waves per SIMD; BS = 2, 4 (18 KiB): 2 by LDS, so up to 3 is free.
+#ifdef JPEGX_U8_WPE   // A/B builds (microbench/build_variant.sh): another budget
 #define JPEGX_U8_OCC __attribute__((amdgpu_waves_per_eu(JPEGX_U8_WPE, JPEGX_U8_WPE)))
 #else
-#define JPEGX_U8_OCC
+#define JPEGX_U8_OCC __attribute__((amdgpu_waves_per_eu(BS == 1 ? 5 : 2)))
 #endif
 template <bool DC_EXACT, int BS, bool NT>
 __global__ __launch_bounds__(64) JPEGX_U8_OCC void k_forward_fused_u8(const unsigned char *__restrict__ in, size_t pitch, int wb,
@@ -985,9 +1002,14 @@ __global__ __launch_bounds__(64) JPEGX_U8_OCC void k_forward_fused_u8(const unsi
     // and 3 % -- 24.3 vs 25.1 Gblocks/s -- while BS = 2 gains 6 % and BS = 4, which also re-read its samples from
     // memory, 9 %: profiles/r02_ab_u8_exact_tier.txt)
     constexpr bool TABBED = BS != 1;
-    constexpr int U8_PATCH = FRONT + SCRATCH_DOUBLES * 8, U8_TAB = U8_PATCH + 128, U8_XBLK = U8_TAB + (TABBED ? 1024 : 0);
-    __shared__ __attribute__((aligned(16))) unsigned char lds[U8_XBLK + (BS == 4 ? 128 : 0)];
-    double *sA = reinterpret_cast<double *>(lds + FRONT);
+    // BS = 1: the input rows fill only the first 4 KiB of the 8 KiB that become the output tile, so the exact tier's
+    // scratch and patch area live in the second half (dead before the tile is written): 8 KiB of LDS in all = 20
+    // waves per CU, which the 94 registers of this variant allow (5 per SIMD)
+    constexpr int SCR = (BS == 1) ? IN_BYTES : FRONT;
+    static_assert(BS != 1 || IN_BYTES + SCRATCH_DOUBLES * 8 + 128 <= TILE_BYTES, "scratch fits behind the rows");
+    constexpr int U8_PATCH = SCR + SCRATCH_DOUBLES * 8, U8_TAB = U8_PATCH + 128, U8_XBLK = U8_TAB + (TABBED ? 1024 : 0);
+    __shared__ __attribute__((aligned(16))) unsigned char lds[BS == 1 ? TILE_BYTES : U8_XBLK + (BS == 4 ? 128 : 0)];
+    double *sA = reinterpret_cast<double *>(lds + SCR);
     double *sM = sA + 64;
     int16_t *sP = reinterpret_cast<int16_t *>(lds + U8_PATCH);
 
@@ -1083,6 +1105,11 @@ __global__ __launch_bounds__(64) JPEGX_U8_OCC void k_forward_fused_u8(const unsi
             for (int c = 0; c < 4; ++c) {
                 v[r * 8 + c] = (float)((t.x >> (8 * c)) & 0xFFu);
                 v[r * 8 + 4 + c] = (float)((t.y >> (8 * c)) & 0xFFu);
+                // one v_cvt_f32_ubyteN each, and opaque from here on: left to itself the compiler moves the first
+                // butterfly stage in front of the conversion (v_add/sub_u32_sdwa on the bytes, then v_cvt_f32_i32),
+                // which swaps 64 full-rate float adds for 64 SDWA operations that issue at 0.6 of that rate
+                // (profiles/r03_valu_rate.txt)
+                asm volatile("" : "+v"(v[r * 8 + c]), "+v"(v[r * 8 + 4 + c]));
             }
         }
     } else {
@@ -1106,7 +1133,7 @@ __global__ __launch_bounds__(64) JPEGX_U8_OCC void k_forward_fused_u8(const unsi
     unsigned pk[32];
     const float worst = quantise_zigzag_pack<true, DC_EXACT>(v, prm, E, pk);
 
-    unsigned long long flagged = __ballot(valid && !(worst < 0.5f));
+    unsigned long long flagged = __ballot(valid && !(worst < JPEGX_SAFE_HALF));
     census(counters, flagged, nblk - g0, lane);
     if (prm.tune & 1) flagged = 0;
     if (flagged) {      // exact tier: samples from the rows still resident in LDS (BS = 4: from the owner's tile sums)
@@ -1150,6 +1177,17 @@ __global__ __launch_bounds__(64) JPEGX_U8_OCC void k_forward_fused_u8(const unsi
         }
     }
 
+    if (prm.tune & 4) {
+        // A/B (JPEGX_F_TUNE_DIRECT_STORE): every lane stores its own 128 bytes, eight 16-byte pieces at a 128-byte
+        // lane stride, default cache policy so that L2 merges the pieces of a line -- no LDS tile, no barriers
+        if (valid) {
+            unsigned char *dst = reinterpret_cast<unsigned char *>(out) + (size_t)(g0 + lane) * 128;
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                st_u32x4<false>(dst + c * 16, u32x4{pk[c * 4 + 0], pk[c * 4 + 1], pk[c * 4 + 2], pk[c * 4 + 3]});
+        }
+        return;
+    }
     __syncthreads();    // the input rows are dead: reuse the front of LDS as the swizzled output tile
 #pragma unroll
     for (int c = 0; c < 8; ++c)
@@ -1483,6 +1521,7 @@ int jpegx_forward_fused_u8(const uint8_t *d_in, int H, int W, ptrdiff_t pitch, i
     if (max_abs_multiplier(qp) > 2.0f)   // the uint8 kernels pack without saturating (see launch_forward)
         return fail(JPEGX_E_UNSUPPORTED, "forward_u8: a divisor below 0.5 can overflow int16; use the fp32 entry (it saturates)");
     if (flags & JPEGX_F_TUNE_SKIP_EXACT) qp.tune |= 1;
+    if (flags & JPEGX_F_TUNE_DIRECT_STORE) qp.tune |= 4;
     const int wb = W / 8, nblk = (H / 8) * wb;
     const dim3 grid((nblk + 63) / 64), block(64);
     hipStream_t st = (hipStream_t)stream;

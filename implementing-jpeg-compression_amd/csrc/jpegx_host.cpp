@@ -74,6 +74,7 @@ extern "C" int jpegx_host_entropy_decode(const uint8_t *h_bytes, size_t nbytes, 
                 n += 15;
                 continue;
             }
+            if (size == 1) return fail("ValueError: run-length code with a sign bit but no amplitude bits (size 1)");   // rle_byte_stream.py:35-42
             if (cur.bits_left() < 8 + size) return fail("entropy stream ends inside an amplitude");
             const unsigned bits = (unsigned)((w << 8) >> (64 - size));
             cur.bitpos += 8 + size;
@@ -83,6 +84,9 @@ extern "C" int jpegx_host_entropy_decode(const uint8_t *h_bytes, size_t nbytes, 
             blk[n++] = (int16_t)((bits >> (size - 1)) ? (int)mag : -(int)mag);       // sign bit '1' = positive
         }
     }
+    // bytes (whole blocks) behind the last block: the reference parses them too and then fails in its reshape
+    // (run_length_encoding.py:77-79)
+    if (cur.bits_left() > 0) return fail("ValueError: the entropy stream holds more than the plane's blocks");
     return JPEGX_OK;
 }
 

@@ -1,15 +1,20 @@
 // jpegx_hostpipe.cpp -- the host-pointer side of libjpegx.so done natively: per-device pools of
-// device buffers, a stream and pinned staging memory (grow-only, reused across calls instead of a
-// hipMalloc + hipStreamCreate per call), and the whole compress_band job for one plane
+// device buffers, streams and pinned staging memory (grow-only, reused across calls instead of a
+// hipMalloc + hipStreamCreate per call), the whole compress_band / decompress_band job for one plane
 // (range check + narrowing of wide integer bands, upload, fused forward, device entropy stage,
-// download straight into the caller's bytes) in two C calls.
+// download straight into the caller's bytes) and, round 3, the whole-IMAGE jobs: the bands of one
+// picture through one lock on two alternating streams, so that the upload and transform of band k + 1
+// overlap the entropy stage and the download of band k.
 //
-// Replaces, for 8-bit bands with transform 'DCT' / dct_size 8, the loop of pipeline/__init__.py:71-76
-// of the reference (steps 1..8 on one band; step 0 padding stays with the caller).
+// Replaces, for 8-bit bands with transform 'DCT' / dct_size 8, the loops of pipeline/__init__.py:71-76,
+// 79-88 (one band) and :102-124 (Jpeg.compress / Jpeg.decompress: Y, Cb, Cr one after another) of the
+// reference; step 0 padding stays with the caller.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include <atomic>
 #include <mutex>
@@ -59,29 +64,96 @@ struct Span {
         cap = want;
         return JPEGX_OK;
     }
+    void release()
+    {
+        if (p) { if (pinned) (void)hipHostFree(p); else (void)hipFree(p); }
+        p = nullptr;
+        cap = 0;
+    }
 };
 
 constexpr int MAX_DEVICES = 16;
+constexpr int MAX_BANDS = JPEGX_MAX_IMAGE_BANDS;
+
+// the device-side working set of one band
+struct BandSlot {
+    Span d_in, d_zz, d_ws, d_out, d_tmp;
+};
 
 struct DevicePool {
     std::mutex mu;                // one host job at a time per device
-    hipStream_t stream = nullptr;
-    Span d_in, d_zz, d_ws, d_out, d_tmp;
-    Span h_in{nullptr, 0, true}, h_out{nullptr, 0, true};
+    hipStream_t stream = nullptr; // single-band jobs and the host-pointer conveniences
+    hipStream_t aux[2] = {nullptr, nullptr};   // image jobs: bands alternate between these two
+    hipEvent_t ev[MAX_BANDS] = {};
+    BandSlot slot[MAX_BANDS];     // slot 0 doubles as the single-band working set
+    Span d_packed;                // image jobs: the pixel-interleaved picture before it goes down
+    Span h_in{nullptr, 0, true}, h_out{nullptr, 0, true}, h_head{nullptr, 0, true};
     // state between jpegx_host_compress_begin and _finish (the pool stays locked in between)
     bool open = false;
     size_t out_bytes = 0;
-    std::thread::id owner;
 };
 
 DevicePool g_pool[MAX_DEVICES];
 
-int current_pool(DevicePool **pool)
+// The pool this thread holds across C calls (an open compress job) or inside one (a borrowed working set).  Every
+// pooled entry asks here first: a thread that already holds the pool gets JPEGX_E_INVALID instead of locking the
+// non-recursive mutex a second time, and finish / abort / release find THEIR pool whatever the thread's current
+// device has become in the meantime.
+thread_local DevicePool *t_held = nullptr;
+thread_local int t_held_device = -1;
+
+int current_pool(DevicePool **pool, int *device = nullptr)
 {
     int dev = 0;
     HP_TRY(hipGetDevice(&dev));
     if (dev < 0 || dev >= MAX_DEVICES) return fail(JPEGX_E_UNSUPPORTED, "device index beyond the pool table");
     *pool = &g_pool[dev];
+    if (device) *device = dev;
+    return JPEGX_OK;
+}
+
+// lock the current device's pool for this thread (released by unlock_pool)
+int lock_pool(DevicePool **out)
+{
+    DevicePool *pool = nullptr;
+    int dev = 0;
+    int rc = current_pool(&pool, &dev);
+    if (rc) return rc;
+    if (t_held != nullptr)
+        return fail(JPEGX_E_INVALID, t_held->open ? "a compress job is open on this thread: finish or abort it first"
+                                                   : "this thread already holds a device pool");
+    pool->mu.lock();
+    t_held = pool;
+    t_held_device = dev;
+    *out = pool;
+    return JPEGX_OK;
+}
+
+void unlock_pool(DevicePool *pool)
+{
+    if (t_held == pool) {
+        t_held = nullptr;
+        t_held_device = -1;
+        pool->mu.unlock();
+    }
+}
+
+struct PoolLock {     // scope form
+    DevicePool *pool = nullptr;
+    int rc;
+    PoolLock() { rc = lock_pool(&pool); }
+    ~PoolLock() { if (pool) unlock_pool(pool); }
+};
+
+int ensure_streams(DevicePool *pool, bool image)
+{
+    if (!pool->stream) HP_TRY(hipStreamCreateWithFlags(&pool->stream, hipStreamNonBlocking));
+    if (image) {
+        for (int i = 0; i < 2; ++i)
+            if (!pool->aux[i]) HP_TRY(hipStreamCreateWithFlags(&pool->aux[i], hipStreamNonBlocking));
+        for (int i = 0; i < MAX_BANDS; ++i)
+            if (!pool->ev[i]) HP_TRY(hipEventCreateWithFlags(&pool->ev[i], hipEventDisableTiming));
+    }
     return JPEGX_OK;
 }
 
@@ -117,6 +189,92 @@ bool narrow_rows(const T *src, ptrdiff_t src_pitch, int H, int W, uint8_t *dst, 
     return ok;
 }
 
+int check_compress_shape(const void *h_plane, int elem_size, int H, int W, ptrdiff_t pitch, int bs)
+{
+    if (!h_plane) return fail(JPEGX_E_INVALID, "null pointer");
+    if (bs < 1 || bs > 255) return fail(JPEGX_E_UNSUPPORTED, "host_compress supports block_size 1..255");
+    if (H <= 0 || W <= 0 || (H % 8) || (W % 8)) return fail(JPEGX_E_INVALID, "plane height and width (after pooling) must be positive multiples of 8");
+    if ((long long)(H / 8) * (W / 8) > 0x7FFFFFC0LL) return fail(JPEGX_E_INVALID, "more than 2^31 blocks in one plane");
+    if (elem_size != 1 && elem_size != 4 && elem_size != 8) return fail(JPEGX_E_UNSUPPORTED, "host_compress takes uint8, int32 or int64 samples");
+    if (pitch < (ptrdiff_t)W * bs) return fail(JPEGX_E_INVALID, "pitch smaller than the row");
+    const bool fused_pool = bs == 1 || bs == 2 || bs == 4;
+    if (fused_pool && ((W * bs) % 16) != 0) return fail(JPEGX_E_UNSUPPORTED, "host_compress needs rows of a multiple of 16 samples");
+    return JPEGX_OK;
+}
+
+// Steps 1 + 4..7 of one band enqueued on `st`: upload (narrowing wide integers through `stage`, pinned), fused
+// forward (uint8 kernels for block_size 1, 2, 4; mean-pool + all-float64 forward otherwise), sizes + scans.
+// Afterwards the 16-byte head of slot.d_ws holds the total byte count and the error flag.
+int enqueue_front(DevicePool *pool, BandSlot &slot, uint8_t *stage, const void *h_plane, int elem_size, int H, int W, ptrdiff_t pitch,
+                  int bs, int mode, double param, hipStream_t st)
+{
+    const int HH = H * bs, WW = W * bs;
+    const size_t in_bytes = (size_t)HH * WW;
+    const long long nblocks = (long long)(H / 8) * (W / 8);
+    const bool fused_pool = bs == 1 || bs == 2 || bs == 4;   // uint8 kernels with the mean folded in; else pool to float64 first
+    int rc;
+    if ((rc = slot.d_in.ensure(in_bytes)) || (rc = slot.d_zz.ensure((size_t)nblocks * 128)) ||
+        (rc = slot.d_ws.ensure(jpegx_entropy_workspace_bytes(nblocks))))
+        return rc;
+    const uint8_t *src8 = static_cast<const uint8_t *>(h_plane);
+    ptrdiff_t src_pitch = pitch;
+    if (elem_size != 1) {
+        const bool ok = elem_size == 8 ? narrow_rows(static_cast<const int64_t *>(h_plane), pitch, HH, WW, stage, WW)
+                                       : narrow_rows(static_cast<const int32_t *>(h_plane), pitch, HH, WW, stage, WW);
+        if (!ok) return fail(JPEGX_E_UNSUPPORTED, "samples outside 0..255: not an 8-bit band");
+        src8 = stage;
+        src_pitch = WW;
+    }
+    hipError_t e = (src_pitch == WW)
+        ? hipMemcpyAsync(slot.d_in.p, src8, in_bytes, hipMemcpyHostToDevice, st)
+        : hipMemcpy2DAsync(slot.d_in.p, WW, src8, (size_t)src_pitch, WW, HH, hipMemcpyHostToDevice, st);
+    if (e != hipSuccess) return fail(JPEGX_E_HIP, "host to device copy failed");
+    if (fused_pool) {
+        rc = jpegx_forward_fused_u8(static_cast<const uint8_t *>(slot.d_in.p), H, W, WW, bs, mode, param, 0,
+                                    static_cast<int16_t *>(slot.d_zz.p), st);
+    } else {
+        // any other block_size: SubSampling on the device in float64 (exact sum, one division), then the
+        // all-float64 fused forward -- k/9, k/25 ... are not fp32 numbers
+        if ((rc = slot.d_tmp.ensure((size_t)H * W * 8))) return rc;
+        rc = jpegx_mean_pool_f64(slot.d_in.p, 1, H, W, WW, bs, static_cast<double *>(slot.d_tmp.p), W, st);
+        if (!rc)
+            rc = jpegx_forward_fused_f64(static_cast<const double *>(slot.d_tmp.p), H, W, W, mode, param, 0,
+                                         static_cast<int16_t *>(slot.d_zz.p), st);
+    }
+    if (rc) return rc;
+    return jpegx_entropy_sizes(static_cast<const int16_t *>(slot.d_zz.p), nblocks, slot.d_ws.p, st);
+}
+
+// JPEGX_TRACE=1: time stamps of the image jobs' host-side steps on stderr (where does a job's wall time go)
+struct Trace {
+    bool on;
+    double t0;
+    static double now()
+    {
+        struct timespec ts;
+        clock_gettime(CLOCK_MONOTONIC, &ts);
+        return (double)ts.tv_sec * 1e3 + 1e-6 * (double)ts.tv_nsec;
+    }
+    Trace()
+    {
+        const char *e = getenv("JPEGX_TRACE");
+        on = e && *e && *e != '0';
+        t0 = on ? now() : 0.0;
+    }
+    void mark(const char *what, int k = -1) const
+    {
+        if (on) fprintf(stderr, "[jpegx trace +%.3f ms] %s%s%c\n", now() - t0, what, k >= 0 ? " band " : "", k >= 0 ? (char)('0' + k) : ' ');
+    }
+};
+
+int head_verdict(const unsigned long long *head, unsigned long long *total)
+{
+    *total = head[0];
+    if ((unsigned)(head[1] & 0xFFFFFFFFull) != 0)
+        return fail(JPEGX_E_INVALID, "BadRleCodeError: an amplitude needs more than 15 bits (|a| > 16383)");
+    return JPEGX_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -124,165 +282,238 @@ extern "C" {
 int jpegx_host_compress_begin(const void *h_plane, int elem_size, int H, int W, ptrdiff_t pitch, int bs, int mode,
                               double param, size_t *nbytes)
 {
-    if (!h_plane || !nbytes) return fail(JPEGX_E_INVALID, "null pointer");
-    if (bs < 1 || bs > 255) return fail(JPEGX_E_UNSUPPORTED, "host_compress supports block_size 1..255");
-    const bool fused_pool = bs == 1 || bs == 2 || bs == 4;   // uint8 kernels with the mean folded in; else pool to float64 first
-    if (H <= 0 || W <= 0 || (H % 8) || (W % 8)) return fail(JPEGX_E_INVALID, "plane height and width (after pooling) must be positive multiples of 8");
-    if (elem_size != 1 && elem_size != 4 && elem_size != 8) return fail(JPEGX_E_UNSUPPORTED, "host_compress takes uint8, int32 or int64 samples");
-    const int HH = H * bs, WW = W * bs;
-    if (pitch < WW) return fail(JPEGX_E_INVALID, "pitch smaller than the row");
-    if (fused_pool && (WW % 16) != 0) return fail(JPEGX_E_UNSUPPORTED, "host_compress needs rows of a multiple of 16 samples");
-    DevicePool *pool = nullptr;
-    int rc = current_pool(&pool);
+    if (!nbytes) return fail(JPEGX_E_INVALID, "null pointer");
+    int rc = check_compress_shape(h_plane, elem_size, H, W, pitch, bs);
     if (rc) return rc;
-    pool->mu.lock();
-    auto bail = [&](int code) { pool->mu.unlock(); return code; };
-    if (!pool->stream && hipStreamCreateWithFlags(&pool->stream, hipStreamNonBlocking) != hipSuccess)
-        return bail(fail(JPEGX_E_HIP, "hipStreamCreate failed"));
-    const size_t in_bytes = (size_t)HH * WW;
-    const long long nblocks = (long long)(H / 8) * (W / 8);
-    if ((rc = pool->d_in.ensure(in_bytes)) || (rc = pool->d_zz.ensure((size_t)nblocks * 128)) ||
-        (rc = pool->d_ws.ensure(jpegx_entropy_workspace_bytes(nblocks))))
-        return bail(rc);
+    DevicePool *pool = nullptr;
+    if ((rc = lock_pool(&pool))) return rc;
+    auto bail = [&](int code) { unlock_pool(pool); return code; };
+    if ((rc = ensure_streams(pool, false))) return bail(rc);
+    if (elem_size != 1 && (rc = pool->h_in.ensure((size_t)H * bs * W * bs))) return bail(rc);
+    BandSlot &slot = pool->slot[0];
     hipStream_t st = pool->stream;
-    const uint8_t *src8 = static_cast<const uint8_t *>(h_plane);
-    ptrdiff_t src_pitch = pitch;
-    if (elem_size != 1) {
-        if ((rc = pool->h_in.ensure(in_bytes))) return bail(rc);
-        const bool ok = elem_size == 8
-            ? narrow_rows(static_cast<const int64_t *>(h_plane), pitch, HH, WW, static_cast<uint8_t *>(pool->h_in.p), WW)
-            : narrow_rows(static_cast<const int32_t *>(h_plane), pitch, HH, WW, static_cast<uint8_t *>(pool->h_in.p), WW);
-        if (!ok) return bail(fail(JPEGX_E_UNSUPPORTED, "samples outside 0..255: not an 8-bit band"));
-        src8 = static_cast<const uint8_t *>(pool->h_in.p);
-        src_pitch = WW;
-    }
-    hipError_t e = (src_pitch == WW)
-        ? hipMemcpyAsync(pool->d_in.p, src8, in_bytes, hipMemcpyHostToDevice, st)
-        : hipMemcpy2DAsync(pool->d_in.p, WW, src8, (size_t)src_pitch, WW, HH, hipMemcpyHostToDevice, st);
-    if (e != hipSuccess) return bail(fail(JPEGX_E_HIP, "host to device copy failed"));
-    if (fused_pool) {
-        rc = jpegx_forward_fused_u8(static_cast<const uint8_t *>(pool->d_in.p), H, W, WW, bs, mode, param, 0,
-                                    static_cast<int16_t *>(pool->d_zz.p), st);
-    } else {
-        // any other block_size: SubSampling on the device in float64 (exact sum, one division), then the
-        // all-float64 fused forward -- k/9, k/25 ... are not fp32 numbers
-        if ((rc = pool->d_tmp.ensure((size_t)H * W * 8))) return bail(rc);
-        rc = jpegx_mean_pool_f64(pool->d_in.p, 1, H, W, WW, bs, static_cast<double *>(pool->d_tmp.p), W, st);
-        if (!rc)
-            rc = jpegx_forward_fused_f64(static_cast<const double *>(pool->d_tmp.p), H, W, W, mode, param, 0,
-                                         static_cast<int16_t *>(pool->d_zz.p), st);
-    }
-    if (rc || (rc = jpegx_entropy_sizes(static_cast<const int16_t *>(pool->d_zz.p), nblocks, pool->d_ws.p, st)))
+    if ((rc = enqueue_front(pool, slot, static_cast<uint8_t *>(pool->h_in.p), h_plane, elem_size, H, W, pitch, bs, mode, param, st)))
         return bail(rc);
     unsigned long long total = 0;
-    if ((rc = jpegx_entropy_total(pool->d_ws.p, &total, st))) return bail(rc);      // synchronises
-    if ((rc = pool->d_out.ensure(total ? (size_t)total : 1))) return bail(rc);
-    if ((rc = jpegx_entropy_emit(static_cast<const int16_t *>(pool->d_zz.p), nblocks, pool->d_ws.p,
-                                 static_cast<uint8_t *>(pool->d_out.p), st)))
+    if ((rc = jpegx_entropy_total(slot.d_ws.p, &total, st))) return bail(rc);      // synchronises
+    if ((rc = slot.d_out.ensure(total ? (size_t)total : 1))) return bail(rc);
+    const long long nblocks = (long long)(H / 8) * (W / 8);
+    if ((rc = jpegx_entropy_emit(static_cast<const int16_t *>(slot.d_zz.p), nblocks, slot.d_ws.p,
+                                 static_cast<uint8_t *>(slot.d_out.p), st)))
         return bail(rc);
     pool->open = true;
     pool->out_bytes = (size_t)total;
-    pool->owner = std::this_thread::get_id();
     *nbytes = (size_t)total;
-    return JPEGX_OK;                       // the pool stays locked until _finish / _abort
+    return JPEGX_OK;                       // the pool stays locked (and t_held set) until _finish / _abort
 }
 
 int jpegx_host_compress_finish(uint8_t *h_out)
 {
-    DevicePool *pool = nullptr;
-    int rc = current_pool(&pool);
-    if (rc) return rc;
-    if (!pool->open || pool->owner != std::this_thread::get_id()) return fail(JPEGX_E_INVALID, "no open compress job on this thread and device");
+    DevicePool *pool = t_held;             // this thread's open job, whatever its current device is by now
+    if (!pool || !pool->open) return fail(JPEGX_E_INVALID, "no open compress job on this thread");
     hipError_t e = hipSuccess;
     if (pool->out_bytes) {
         if (!h_out) e = hipErrorInvalidValue;
-        if (e == hipSuccess) e = hipMemcpyAsync(h_out, pool->d_out.p, pool->out_bytes, hipMemcpyDeviceToHost, pool->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(h_out, pool->slot[0].d_out.p, pool->out_bytes, hipMemcpyDeviceToHost, pool->stream);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(pool->stream);
     pool->open = false;
-    pool->mu.unlock();
+    unlock_pool(pool);
     if (e != hipSuccess) return fail(JPEGX_E_HIP, "device to host copy failed");
     return JPEGX_OK;
 }
 
 int jpegx_host_compress_abort(void)
 {
-    DevicePool *pool = nullptr;
-    int rc = current_pool(&pool);
-    if (rc) return rc;
-    if (pool->open && pool->owner == std::this_thread::get_id()) {
+    DevicePool *pool = t_held;
+    if (pool && pool->open) {
         (void)hipStreamSynchronize(pool->stream);
         pool->open = false;
-        pool->mu.unlock();
+        unlock_pool(pool);
     }
     return JPEGX_OK;
 }
 
-namespace {
-// bytes already on the device (pool->d_in, padded) -> int16 stream in pool->d_zz; the caller holds the pool
-int decode_on_device(DevicePool *pool, size_t nbytes, long long nblocks)
+// ---- whole image, forward (pipeline/__init__.py:102-110 + file_format.generate_data, file_format.py:86-93) --------
+// Band k runs on stream k % 2: upload -> fused forward -> sizes / scans -> 16-byte head down to pinned memory ->
+// event.  Once every band's byte count is known the caller is asked ONCE for the destination of the whole result
+// (`alloc`, e.g. a fresh Python bytes object): [prefix][u32 LE count of band 0][band 0][count][band 1] ... -- with
+// the container header as prefix that IS the reference's file, no concatenation on the host afterwards.  The
+// destination's pages are touched by a few host threads (fresh memory: the kernel hands out zeroed pages one fault
+// at a time, which costs more than the copy itself) while the emit kernels run, then every band's bytes are
+// copied from the device straight to their place.
+static void prefault(uint8_t *p, size_t n)
 {
-    hipStream_t st = pool->stream;
+    if (n < (4u << 20)) return;
+    const unsigned hw = std::thread::hardware_concurrency();
+    const int nthreads = hw >= 8 ? 8 : (hw ? (int)hw : 1);
+    auto work = [&](size_t a, size_t b) {
+        for (size_t o = a; o < b; o += 4096) reinterpret_cast<volatile uint8_t *>(p)[o] = 0;
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < nthreads; ++t) th.emplace_back(work, n * t / nthreads, n * (t + 1) / nthreads);
+    work(0, n / nthreads);
+    for (auto &t : th) t.join();
+}
+
+int jpegx_host_compress_image(const void *const *h_planes, int nbands, int elem_size, int H, int W, ptrdiff_t pitch, int bs,
+                              int mode, double param, const void *prefix, size_t prefix_len, int length_prefixes,
+                              jpegx_alloc_fn alloc, void *user, size_t *nbytes)
+{
+    if (!h_planes || !alloc || !nbytes || (prefix_len && !prefix)) return fail(JPEGX_E_INVALID, "null pointer");
+    if (nbands < 1 || nbands > MAX_BANDS) return fail(JPEGX_E_INVALID, "compress_image takes 1..JPEGX_MAX_IMAGE_BANDS bands");
     int rc;
-    if ((rc = pool->d_ws.ensure(jpegx_decode::phase1_bytes(nbytes))) || (rc = pool->d_zz.ensure((size_t)nblocks * 128))) return rc;
-    jpegx_decode::enqueue_phase1(static_cast<const uint8_t *>(pool->d_in.p), nbytes, pool->d_ws.p, st);
+    for (int k = 0; k < nbands; ++k)
+        if ((rc = check_compress_shape(h_planes[k], elem_size, H, W, pitch, bs))) return rc;
+    PoolLock lock;
+    if (lock.rc) return lock.rc;
+    DevicePool *pool = lock.pool;
+    if ((rc = ensure_streams(pool, true))) return rc;
+    const size_t in_bytes = (size_t)H * bs * W * bs;
+    const long long nblocks = (long long)(H / 8) * (W / 8);
+    if ((rc = pool->h_head.ensure(16 * MAX_BANDS))) return rc;
+    if (elem_size != 1 && (rc = pool->h_in.ensure(in_bytes * nbands))) return rc;
+    unsigned long long *heads = static_cast<unsigned long long *>(pool->h_head.p);
+    auto drain = [&]() { (void)hipStreamSynchronize(pool->aux[0]); (void)hipStreamSynchronize(pool->aux[1]); };
+    const Trace tr;
+    tr.mark("compress_image: pool ready");
+    for (int k = 0; k < nbands; ++k) {
+        hipStream_t st = pool->aux[k & 1];
+        uint8_t *stage = elem_size != 1 ? static_cast<uint8_t *>(pool->h_in.p) + in_bytes * k : nullptr;
+        rc = enqueue_front(pool, pool->slot[k], stage, h_planes[k], elem_size, H, W, pitch, bs, mode, param, st);
+        if (!rc && hipMemcpyAsync(heads + 2 * k, pool->slot[k].d_ws.p, 16, hipMemcpyDeviceToHost, st) != hipSuccess)
+            rc = fail(JPEGX_E_HIP, "device to host copy failed");
+        if (!rc && hipEventRecord(pool->ev[k], st) != hipSuccess) rc = fail(JPEGX_E_HIP, "hipEventRecord failed");
+        if (rc) { drain(); return rc; }
+        tr.mark("front enqueued", k);
+    }
+    size_t total_all = prefix_len;
+    size_t offset[MAX_BANDS] = {};
+    for (int k = 0; k < nbands; ++k) {
+        if (hipEventSynchronize(pool->ev[k]) != hipSuccess) { drain(); return fail(JPEGX_E_HIP, "hipEventSynchronize failed"); }
+        unsigned long long total = 0;
+        if ((rc = head_verdict(heads + 2 * k, &total))) { drain(); return rc; }
+        if (length_prefixes && total > 0xFFFFFFFFull) { drain(); return fail(JPEGX_E_INVALID, "a band's stream does not fit the container's 32-bit length field"); }
+        nbytes[k] = (size_t)total;
+        offset[k] = total_all + (length_prefixes ? 4 : 0);
+        total_all = offset[k] + (size_t)total;
+        // the emit kernel needs only the device-side offsets: enqueue it now, the destination comes later
+        BandSlot &slot = pool->slot[k];
+        if ((rc = slot.d_out.ensure(total ? (size_t)total : 1)) ||
+            (rc = jpegx_entropy_emit(static_cast<const int16_t *>(slot.d_zz.p), nblocks, slot.d_ws.p, static_cast<uint8_t *>(slot.d_out.p),
+                                     pool->aux[k & 1]))) {
+            drain();
+            return rc;
+        }
+    }
+    tr.mark("sizes known, emits enqueued");
+    uint8_t *dst = static_cast<uint8_t *>(alloc(user, total_all));
+    if (!dst && total_all) { drain(); return fail(JPEGX_E_INVALID, "the allocator returned no destination"); }
+    tr.mark("destination allocated");
+    prefault(dst, total_all);
+    tr.mark("destination touched");
+    if (prefix_len) memcpy(dst, prefix, prefix_len);
+    for (int k = 0; k < nbands; ++k) {
+        if (length_prefixes) {
+            const uint32_t n32 = (uint32_t)nbytes[k];
+            const uint8_t le[4] = {(uint8_t)n32, (uint8_t)(n32 >> 8), (uint8_t)(n32 >> 16), (uint8_t)(n32 >> 24)};   // struct '<L'
+            memcpy(dst + offset[k] - 4, le, 4);
+        }
+        if (nbytes[k] && hipMemcpyAsync(dst + offset[k], pool->slot[k].d_out.p, nbytes[k], hipMemcpyDeviceToHost, pool->aux[k & 1]) != hipSuccess) {
+            drain();
+            return fail(JPEGX_E_HIP, "device to host copy failed");
+        }
+        tr.mark("download enqueued", k);
+    }
+    HP_TRY(hipStreamSynchronize(pool->aux[0]));
+    HP_TRY(hipStreamSynchronize(pool->aux[1]));
+    tr.mark("compress_image: done");
+    return JPEGX_OK;
+}
+
+}  // extern "C"
+
+namespace {
+// bytes already on the device (slot.d_in, padded) -> int16 stream in slot.d_zz; the caller holds the pool
+int decode_on_device(BandSlot &slot, size_t nbytes, long long nblocks, hipStream_t st)
+{
+    int rc;
+    if ((rc = slot.d_ws.ensure(jpegx_decode::phase1_bytes(nbytes))) || (rc = slot.d_zz.ensure((size_t)nblocks * 128))) return rc;
+    jpegx_decode::enqueue_phase1(static_cast<const uint8_t *>(slot.d_in.p), nbytes, slot.d_ws.p, st);
     unsigned head[4] = {0, 0, 0, 0};
-    HP_TRY(hipMemcpyAsync(head, pool->d_ws.p, 16, hipMemcpyDeviceToHost, st));
+    HP_TRY(hipMemcpyAsync(head, slot.d_ws.p, 16, hipMemcpyDeviceToHost, st));
     HP_TRY(hipStreamSynchronize(st));
     const unsigned ncand = head[0];
     if (ncand == 0 || (long long)ncand < nblocks) return fail(JPEGX_E_INVALID, "entropy stream holds fewer blocks than the plane has");
-    if ((rc = pool->d_tmp.ensure(jpegx_decode::phase2_bytes(ncand, nblocks)))) return rc;
-    jpegx_decode::enqueue_phase2(static_cast<const uint8_t *>(pool->d_in.p), nbytes, nblocks, pool->d_ws.p, ncand, pool->d_tmp.p,
-                                 static_cast<int16_t *>(pool->d_zz.p), st);
+    if ((rc = slot.d_tmp.ensure(jpegx_decode::phase2_bytes(ncand, nblocks)))) return rc;
+    jpegx_decode::enqueue_phase2(static_cast<const uint8_t *>(slot.d_in.p), nbytes, nblocks, slot.d_ws.p, ncand, slot.d_tmp.p,
+                                 static_cast<int16_t *>(slot.d_zz.p), st);
     HP_TRY(hipGetLastError());
     return JPEGX_OK;
 }
 
-int decode_status(DevicePool *pool)     // after the stream has been synchronised
+int decode_status(BandSlot &slot)     // after the stream has been synchronised
 {
     unsigned head[4] = {0, 0, 0, 0};
-    HP_TRY(hipMemcpy(head, pool->d_ws.p, 16, hipMemcpyDeviceToHost));
+    HP_TRY(hipMemcpy(head, slot.d_ws.p, 16, hipMemcpyDeviceToHost));
     if (head[1] != 0) return fail(JPEGX_E_INVALID, "entropy stream is not a sequence of well-formed blocks (device decoder)");
     return JPEGX_OK;
 }
+
+int check_decompress_shape(const uint8_t *h_bytes, size_t nbytes, int H, int W, int bs)
+{
+    if (!h_bytes) return fail(JPEGX_E_INVALID, "null host pointer");
+    if (H <= 0 || W <= 0 || (H % 8) || (W % 8)) return fail(JPEGX_E_INVALID, "plane height and width must be positive multiples of 8");
+    if ((long long)(H / 8) * (W / 8) > 0x7FFFFFC0LL) return fail(JPEGX_E_INVALID, "block count must be in 1 .. 2^31-64");
+    if (bs < 1 || bs > 255) return fail(JPEGX_E_UNSUPPORTED, "host_decompress supports block_size 1..255");
+    if (nbytes == 0 || nbytes >= 0xFFFFFFF0ull) return fail(JPEGX_E_INVALID, "entropy stream empty or beyond 4 GiB");
+    return JPEGX_OK;
+}
+
+// upload + device entropy decoding + fused inverse (clamp, SubSampling.invert) of one band into slot.d_out
+// ([H*bs][dev_pitch] bytes), all on `st`
+int enqueue_back(BandSlot &slot, const uint8_t *h_bytes, size_t nbytes, int H, int W, int bs, int mode, double param,
+                 ptrdiff_t dev_pitch, hipStream_t st)
+{
+    const long long nblocks = (long long)(H / 8) * (W / 8);
+    int rc;
+    if ((rc = slot.d_in.ensure(nbytes + 16)) || (rc = slot.d_out.ensure((size_t)H * bs * dev_pitch))) return rc;
+    HP_TRY(hipMemsetAsync(static_cast<uint8_t *>(slot.d_in.p) + (nbytes & ~(size_t)3), 0, 16 + (nbytes & 3), st));   // zero tail (whole dwords)
+    HP_TRY(hipMemcpyAsync(slot.d_in.p, h_bytes, nbytes, hipMemcpyHostToDevice, st));
+    if ((rc = decode_on_device(slot, nbytes, nblocks, st))) return rc;
+    return jpegx_inverse_fused_u8_inflated(static_cast<const int16_t *>(slot.d_zz.p), H, W, mode, param, 0, bs,
+                                           static_cast<uint8_t *>(slot.d_out.p), dev_pitch, st);
+}
 }  // namespace
+
+extern "C" {
 
 // Inverse of jpegx_host_compress_*: the whole decompress_band job for one plane (pipeline/__init__.py:79-88 for
 // transform 'DCT', dct_size 8): bytes up, entropy decoding ON THE DEVICE (jpegx_entropy_decode.hip), fused
-// inverse with clamp and SubSampling.invert, uint8 samples down.  h_out: [H*bs][out_pitch] bytes.
+// inverse with clamp and SubSampling.invert (any block_size), uint8 samples down.  h_out: [H*bs][out_pitch] bytes.
 static int decompress_plane_locked(DevicePool *pool, const uint8_t *h_bytes, size_t nbytes, int H, int W, int bs, int mode,
                                    double param, uint8_t *h_out, ptrdiff_t out_pitch)
 {
-    if (!h_bytes || !h_out) return fail(JPEGX_E_INVALID, "null host pointer");
-    if (H <= 0 || W <= 0 || (H % 8) || (W % 8)) return fail(JPEGX_E_INVALID, "plane height and width must be positive multiples of 8");
-    if (bs != 1 && bs != 2 && bs != 4) return fail(JPEGX_E_UNSUPPORTED, "host_decompress supports block_size 1, 2 and 4");
-    if (nbytes == 0 || nbytes >= 0xFFFFFFF0ull) return fail(JPEGX_E_INVALID, "entropy stream empty or beyond 4 GiB");
-    if (out_pitch < (ptrdiff_t)W * bs || (out_pitch % (bs == 1 ? 8 : 16)) != 0) return fail(JPEGX_E_INVALID, "output pitch too small or misaligned");
-    const long long nblocks = (long long)(H / 8) * (W / 8);
-    int rc;
-    if (!pool->stream && hipStreamCreateWithFlags(&pool->stream, hipStreamNonBlocking) != hipSuccess) return fail(JPEGX_E_HIP, "hipStreamCreate failed");
+    int rc = check_decompress_shape(h_bytes, nbytes, H, W, bs);
+    if (rc) return rc;
+    if (!h_out) return fail(JPEGX_E_INVALID, "null host pointer");
+    if (out_pitch < (ptrdiff_t)W * bs || (out_pitch % ((bs == 2 || bs == 4) ? 16 : 8)) != 0)
+        return fail(JPEGX_E_INVALID, "output pitch too small or misaligned");
+    if ((rc = ensure_streams(pool, false))) return rc;
     hipStream_t st = pool->stream;
-    const size_t out_bytes = (size_t)H * bs * out_pitch;
-    if ((rc = pool->d_in.ensure(nbytes + 16)) || (rc = pool->d_out.ensure(out_bytes))) return rc;
-    HP_TRY(hipMemsetAsync(static_cast<uint8_t *>(pool->d_in.p) + (nbytes & ~(size_t)3), 0, 16 + (nbytes & 3), st));   // zero tail (whole dwords)
-    HP_TRY(hipMemcpyAsync(pool->d_in.p, h_bytes, nbytes, hipMemcpyHostToDevice, st));
-    if ((rc = decode_on_device(pool, nbytes, nblocks))) return rc;
-    if ((rc = jpegx_inverse_fused_u8_inflated(static_cast<const int16_t *>(pool->d_zz.p), H, W, mode, param, 0, bs,
-                                              static_cast<uint8_t *>(pool->d_out.p), out_pitch, st)))
-        return rc;
-    HP_TRY(hipMemcpyAsync(h_out, pool->d_out.p, out_bytes, hipMemcpyDeviceToHost, st));
+    BandSlot &slot = pool->slot[0];
+    if ((rc = enqueue_back(slot, h_bytes, nbytes, H, W, bs, mode, param, out_pitch, st))) return rc;
+    HP_TRY(hipMemcpyAsync(h_out, slot.d_out.p, (size_t)H * bs * out_pitch, hipMemcpyDeviceToHost, st));
     HP_TRY(hipStreamSynchronize(st));
-    return decode_status(pool);
+    return decode_status(slot);
 }
 
 int jpegx_host_decompress_plane(const uint8_t *h_bytes, size_t nbytes, int H, int W, int bs, int mode, double param,
                                 uint8_t *h_out, ptrdiff_t out_pitch)
 {
-    DevicePool *pool = nullptr;
-    int rc = current_pool(&pool);
-    if (rc) return rc;
-    std::lock_guard<std::mutex> lock(pool->mu);
-    return decompress_plane_locked(pool, h_bytes, nbytes, H, W, bs, mode, param, h_out, out_pitch);
+    PoolLock lock;
+    if (lock.rc) return lock.rc;
+    return decompress_plane_locked(lock.pool, h_bytes, nbytes, H, W, bs, mode, param, h_out, out_pitch);
 }
 
 // The same, handing back what the reference's decompress_band returns: a [rows][cols] int64 array (the band
@@ -295,10 +526,10 @@ int jpegx_host_decompress_plane_i64(const uint8_t *h_bytes, size_t nbytes, int H
         return fail(JPEGX_E_INVALID, "bad output shape");
     const ptrdiff_t pitch = ((ptrdiff_t)W * bs + 15) / 16 * 16;
     const size_t stage_bytes = (size_t)H * bs * pitch;
-    DevicePool *pool = nullptr;
-    int rc = current_pool(&pool);
-    if (rc) return rc;
-    std::lock_guard<std::mutex> lock(pool->mu);          // held to the end: the staging span belongs to this job
+    PoolLock lock;                                         // held to the end: the staging span belongs to this job
+    if (lock.rc) return lock.rc;
+    DevicePool *pool = lock.pool;
+    int rc;
     if ((rc = pool->h_out.ensure(stage_bytes))) return rc;
     uint8_t *stage = static_cast<uint8_t *>(pool->h_out.p);
     if ((rc = decompress_plane_locked(pool, h_bytes, nbytes, H, W, bs, mode, param, stage, pitch))) return rc;
@@ -321,25 +552,89 @@ int jpegx_host_decompress_plane_i64(const uint8_t *h_bytes, size_t nbytes, int H
     return JPEGX_OK;
 }
 
+// ---- whole image, inverse (pipeline/__init__.py:112-124) ---------------------------------------------------------
+// The bands of one picture on two alternating streams; the samples come back either as `nbands` planes stacked
+// behind each other ([band][H*bs][out_pitch], interleave = 0) or as the pixel-interleaved array PIL wants
+// ([H*bs][W*bs][nbands] with rows `out_pitch` bytes apart, interleave = 1: np.dstack on the host costs more than the
+// whole device pipeline), cropped to rows x cols.
+int jpegx_host_decompress_image(const uint8_t *const *h_bytes, const size_t *nbytes, int nbands, int H, int W, int bs, int mode,
+                                double param, uint8_t *h_out, ptrdiff_t out_pitch, int rows, int cols, int interleave)
+{
+    if (!h_bytes || !nbytes || !h_out) return fail(JPEGX_E_INVALID, "null pointer");
+    if (nbands < 1 || nbands > MAX_BANDS) return fail(JPEGX_E_INVALID, "decompress_image takes 1..JPEGX_MAX_IMAGE_BANDS bands");
+    int rc;
+    for (int k = 0; k < nbands; ++k)
+        if ((rc = check_decompress_shape(h_bytes[k], nbytes[k], H, W, bs))) return rc;
+    if (rows <= 0 || cols <= 0 || rows > (long long)H * bs || cols > (long long)W * bs) return fail(JPEGX_E_INVALID, "bad output shape");
+    if (out_pitch < (ptrdiff_t)cols * (interleave ? nbands : 1)) return fail(JPEGX_E_INVALID, "output pitch smaller than the row");
+    const ptrdiff_t dev_pitch = ((ptrdiff_t)W * bs + 15) / 16 * 16;
+    PoolLock lock;
+    if (lock.rc) return lock.rc;
+    DevicePool *pool = lock.pool;
+    if ((rc = ensure_streams(pool, true))) return rc;
+    const size_t packed_pitch = (size_t)cols * nbands;
+    if (interleave && (rc = pool->d_packed.ensure((size_t)rows * packed_pitch))) return rc;      // before anything is enqueued
+    // the result array is usually fresh memory: touch its pages on a helper thread while the bands are uploaded and decoded
+    const size_t out_span = interleave ? (size_t)rows * out_pitch : (size_t)nbands * rows * out_pitch;
+    std::thread toucher(prefault, h_out, out_span);
+    struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{toucher};
+    auto drain = [&]() { (void)hipStreamSynchronize(pool->aux[0]); (void)hipStreamSynchronize(pool->aux[1]); };
+    for (int k = 0; k < nbands; ++k) {
+        hipStream_t st = pool->aux[k & 1];
+        if ((rc = enqueue_back(pool->slot[k], h_bytes[k], nbytes[k], H, W, bs, mode, param, dev_pitch, st))) { drain(); return rc; }
+        if (!interleave) {
+            if (hipMemcpy2DAsync(h_out + (size_t)k * rows * out_pitch, (size_t)out_pitch, pool->slot[k].d_out.p, (size_t)dev_pitch,
+                                 (size_t)cols, (size_t)rows, hipMemcpyDeviceToHost, st) != hipSuccess) {
+                drain();
+                return fail(JPEGX_E_HIP, "device to host copy failed");
+            }
+        } else if (hipEventRecord(pool->ev[k], st) != hipSuccess) {
+            drain();
+            return fail(JPEGX_E_HIP, "hipEventRecord failed");
+        }
+    }
+    if (interleave) {
+        // the packing kernel runs on stream 0 behind every band
+        hipStream_t st = pool->aux[0];
+        const void *planes[MAX_BANDS] = {};
+        for (int k = 0; k < nbands; ++k) {
+            planes[k] = pool->slot[k].d_out.p;
+            if (k != 0 && hipStreamWaitEvent(st, pool->ev[k], 0) != hipSuccess) { drain(); return fail(JPEGX_E_HIP, "hipStreamWaitEvent failed"); }
+        }
+        uint8_t *packed = static_cast<uint8_t *>(pool->d_packed.p);
+        if ((rc = jpegx_interleave_u8(planes, nbands, rows, cols, dev_pitch, packed, (ptrdiff_t)packed_pitch, st))) { drain(); return rc; }
+        if (hipMemcpy2DAsync(h_out, (size_t)out_pitch, packed, packed_pitch, packed_pitch, (size_t)rows, hipMemcpyDeviceToHost, st) != hipSuccess) {
+            drain();
+            return fail(JPEGX_E_HIP, "device to host copy failed");
+        }
+    }
+    HP_TRY(hipStreamSynchronize(pool->aux[0]));
+    HP_TRY(hipStreamSynchronize(pool->aux[1]));
+    for (int k = 0; k < nbands; ++k)
+        if ((rc = decode_status(pool->slot[k]))) return rc;
+    return JPEGX_OK;
+}
+
 // bytes -> int16 [nblocks][64] on the device, host arrays in and out (what jpegx_host_entropy_decode does on the CPU)
 int jpegx_host_entropy_decode_gpu(const uint8_t *h_bytes, size_t nbytes, long long nblocks, int16_t *h_zz)
 {
     if (!h_bytes || !h_zz) return fail(JPEGX_E_INVALID, "null host pointer");
     if (nblocks <= 0 || nblocks > 0x7FFFFFC0LL) return fail(JPEGX_E_INVALID, "block count must be in 1 .. 2^31-64");
     if (nbytes == 0 || nbytes >= 0xFFFFFFF0ull) return fail(JPEGX_E_INVALID, "entropy stream empty or beyond 4 GiB");
-    DevicePool *pool = nullptr;
-    int rc = current_pool(&pool);
-    if (rc) return rc;
-    std::lock_guard<std::mutex> lock(pool->mu);
-    if (!pool->stream && hipStreamCreateWithFlags(&pool->stream, hipStreamNonBlocking) != hipSuccess) return fail(JPEGX_E_HIP, "hipStreamCreate failed");
+    PoolLock lock;
+    if (lock.rc) return lock.rc;
+    DevicePool *pool = lock.pool;
+    int rc;
+    if ((rc = ensure_streams(pool, false))) return rc;
     hipStream_t st = pool->stream;
-    if ((rc = pool->d_in.ensure(nbytes + 16))) return rc;
-    HP_TRY(hipMemsetAsync(static_cast<uint8_t *>(pool->d_in.p) + (nbytes & ~(size_t)3), 0, 16 + (nbytes & 3), st));
-    HP_TRY(hipMemcpyAsync(pool->d_in.p, h_bytes, nbytes, hipMemcpyHostToDevice, st));
-    if ((rc = decode_on_device(pool, nbytes, nblocks))) return rc;
-    HP_TRY(hipMemcpyAsync(h_zz, pool->d_zz.p, (size_t)nblocks * 128, hipMemcpyDeviceToHost, st));
+    BandSlot &slot = pool->slot[0];
+    if ((rc = slot.d_in.ensure(nbytes + 16))) return rc;
+    HP_TRY(hipMemsetAsync(static_cast<uint8_t *>(slot.d_in.p) + (nbytes & ~(size_t)3), 0, 16 + (nbytes & 3), st));
+    HP_TRY(hipMemcpyAsync(slot.d_in.p, h_bytes, nbytes, hipMemcpyHostToDevice, st));
+    if ((rc = decode_on_device(slot, nbytes, nblocks, st))) return rc;
+    HP_TRY(hipMemcpyAsync(h_zz, slot.d_zz.p, (size_t)nblocks * 128, hipMemcpyDeviceToHost, st));
     HP_TRY(hipStreamSynchronize(st));
-    return decode_status(pool);
+    return decode_status(slot);
 }
 
 // used by host_roundtrip (jpegx_internal.h): the synchronous host-pointer conveniences borrow the pool's
@@ -347,42 +642,38 @@ int jpegx_host_entropy_decode_gpu(const uint8_t *h_bytes, size_t nbytes, long lo
 int jpegx_internal_pool_acquire(size_t in_bytes, size_t out_bytes, void **d_in, void **d_out, void **stream)
 {
     DevicePool *pool = nullptr;
-    int rc = current_pool(&pool);
+    int rc = lock_pool(&pool);
     if (rc) return rc;
-    pool->mu.lock();
-    if (!pool->stream && hipStreamCreateWithFlags(&pool->stream, hipStreamNonBlocking) != hipSuccess) {
-        pool->mu.unlock();
-        return fail(JPEGX_E_HIP, "hipStreamCreate failed");
-    }
-    if ((rc = pool->d_in.ensure(in_bytes ? in_bytes : 1)) || (rc = pool->d_out.ensure(out_bytes ? out_bytes : 1))) {
-        pool->mu.unlock();
+    if ((rc = ensure_streams(pool, false)) || (rc = pool->slot[0].d_in.ensure(in_bytes ? in_bytes : 1)) ||
+        (rc = pool->slot[0].d_out.ensure(out_bytes ? out_bytes : 1))) {
+        unlock_pool(pool);
         return rc;
     }
-    *d_in = pool->d_in.p;
-    *d_out = pool->d_out.p;
+    *d_in = pool->slot[0].d_in.p;
+    *d_out = pool->slot[0].d_out.p;
     *stream = pool->stream;
     return JPEGX_OK;
 }
 
 void jpegx_internal_pool_release(void)
 {
-    DevicePool *pool = nullptr;
-    if (current_pool(&pool) == JPEGX_OK) pool->mu.unlock();
+    if (t_held && !t_held->open) unlock_pool(t_held);      // the pool this thread borrowed, not "the current device's"
 }
 
 // release everything the pools hold on the current device (tests; long-lived processes that are done)
 int jpegx_host_pool_release(void)
 {
-    DevicePool *pool = nullptr;
-    int rc = current_pool(&pool);
-    if (rc) return rc;
-    std::lock_guard<std::mutex> lock(pool->mu);
-    for (Span *s : {&pool->d_in, &pool->d_zz, &pool->d_ws, &pool->d_out, &pool->d_tmp, &pool->h_in, &pool->h_out}) {
-        if (s->p) { if (s->pinned) (void)hipHostFree(s->p); else (void)hipFree(s->p); }
-        s->p = nullptr;
-        s->cap = 0;
-    }
+    PoolLock lock;
+    if (lock.rc) return lock.rc;
+    DevicePool *pool = lock.pool;
+    for (BandSlot &b : pool->slot)
+        for (Span *s : {&b.d_in, &b.d_zz, &b.d_ws, &b.d_out, &b.d_tmp}) s->release();
+    for (Span *s : {&pool->d_packed, &pool->h_in, &pool->h_out, &pool->h_head}) s->release();
     if (pool->stream) { (void)hipStreamDestroy(pool->stream); pool->stream = nullptr; }
+    for (hipStream_t &s : pool->aux)
+        if (s) { (void)hipStreamDestroy(s); s = nullptr; }
+    for (hipEvent_t &e : pool->ev)
+        if (e) { (void)hipEventDestroy(e); e = nullptr; }
     return JPEGX_OK;
 }
 

@@ -149,8 +149,9 @@ __device__ __forceinline__ void inv_exact_rows(unsigned rowmask, const unsigned 
 }
 
 // one output row of 8 samples (already rounded; clamped here if asked) -> its place in the output plane
+// inflate == 0: replication factor `rep` known only at run time (any block_size, util.inflate util.py:6-14)
 template <int OUT, bool NT, int inflate>
-__device__ __forceinline__ void store_row(void *base, size_t opitch, int r, const float (&x)[8], int clamp)
+__device__ __forceinline__ void store_row(void *base, size_t opitch, int r, const float (&x)[8], int clamp, int rep = 1)
 {
     if (OUT == 1) {
         unsigned w[4];
@@ -165,22 +166,56 @@ __device__ __forceinline__ void store_row(void *base, size_t opitch, int r, cons
     } else {
         // uint8 rows, optionally with SubSampling.invert fused (util.inflate, util.py:6-14): every
         // sample is replicated inflate x inflate times, the output plane is [H*inflate][W*inflate].
+        // v_cvt_pk_u8_f32 converts with saturation to 0..255 and drops the byte into its place: one instruction per
+        // sample where clamp + conversion + shift/or took three (Normalization.invert, normalization.py:10-14); the
+        // samples are integers already (np.round above), so the conversion's own rounding mode does not matter
         unsigned char *o = reinterpret_cast<unsigned char *>(base);
-        unsigned u[8];
+        if (inflate == 0) {
+            // The row's 8 bytes sit in (lo, hi); its inflated form is 8 * rep bytes = rep 8-byte pieces, written to
+            // `rep` consecutive output rows.  `rep` is wave-uniform, so which sample feeds which output byte is
+            // scalar bookkeeping (sample index s, copies emitted c): no division, no dynamic register indexing --
+            // byte s comes out of the 64-bit pair with a uniform shift.
+            unsigned lo = 0u, hi = 0u;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) u[c] = (unsigned)fminf(fmaxf(x[c], 0.f), 255.f);
-        if (inflate == 1) {
-            st_u32x2<NT>(o + (size_t)r * opitch, u32x2{u[0] | (u[1] << 8) | (u[2] << 16) | (u[3] << 24),
-                                                        u[4] | (u[5] << 8) | (u[6] << 16) | (u[7] << 24)});
+            for (int c = 0; c < 4; ++c) {
+                lo = __builtin_amdgcn_cvt_pk_u8_f32(x[c], c, lo);
+                hi = __builtin_amdgcn_cvt_pk_u8_f32(x[4 + c], c, hi);
+            }
+            const unsigned long long row8 = ((unsigned long long)hi << 32) | lo;
+            int s = 0, c = 0;
+            for (int piece = 0; piece < rep; ++piece) {
+                unsigned w[2] = {0u, 0u};
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const unsigned b = (unsigned)(row8 >> (8 * s)) & 0xFFu;
+                    w[i >> 2] |= b << (8 * (i & 3));
+                    if (++c == rep) { c = 0; ++s; }
+                }
+                for (int a = 0; a < rep; ++a)
+                    st_u32x2<NT>(o + (size_t)(rep * r + a) * opitch + (size_t)piece * 8, u32x2{w[0], w[1]});
+            }
+        } else if (inflate == 1) {
+            unsigned lo = 0u, hi = 0u;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                lo = __builtin_amdgcn_cvt_pk_u8_f32(x[c], c, lo);
+                hi = __builtin_amdgcn_cvt_pk_u8_f32(x[4 + c], c, hi);
+            }
+            st_u32x2<NT>(o + (size_t)r * opitch, u32x2{lo, hi});
         } else if (inflate == 2) {
-            u32x4 w;
-            w.x = (u[0] * 0x0101u) | ((u[1] * 0x0101u) << 16);
-            w.y = (u[2] * 0x0101u) | ((u[3] * 0x0101u) << 16);
-            w.z = (u[4] * 0x0101u) | ((u[5] * 0x0101u) << 16);
-            w.w = (u[6] * 0x0101u) | ((u[7] * 0x0101u) << 16);
-            st_u32x4<NT>(o + (size_t)(2 * r) * opitch, w);
-            st_u32x4<NT>(o + (size_t)(2 * r + 1) * opitch, w);
+            unsigned w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                w[c >> 1] = __builtin_amdgcn_cvt_pk_u8_f32(x[c], 2 * (c & 1), w[c >> 1]);
+                w[c >> 1] = __builtin_amdgcn_cvt_pk_u8_f32(x[c], 2 * (c & 1) + 1, w[c >> 1]);
+            }
+            const u32x4 q = {w[0], w[1], w[2], w[3]};
+            st_u32x4<NT>(o + (size_t)(2 * r) * opitch, q);
+            st_u32x4<NT>(o + (size_t)(2 * r + 1) * opitch, q);
         } else {
+            unsigned u[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) u[c] = __builtin_amdgcn_cvt_pk_u8_f32(x[c], 0, 0u);
             const u32x4 w0 = {u[0] * 0x01010101u, u[1] * 0x01010101u, u[2] * 0x01010101u, u[3] * 0x01010101u};
             const u32x4 w1 = {u[4] * 0x01010101u, u[5] * 0x01010101u, u[6] * 0x01010101u, u[7] * 0x01010101u};
 #pragma unroll
@@ -205,7 +240,7 @@ template <int OUT, bool NT, int INF>
 __global__ __launch_bounds__(64) JPEGX_INV_OCC void k_inverse_fused(const int16_t *__restrict__ in, int wb, int nblk,
                                                       QuantParams prm, int clamp,
                                                       void *__restrict__ outv, size_t opitch,
-                                                      unsigned long long *counters)
+                                                      unsigned long long *counters, int rep)
 {
     // [0, 8 KiB): the wave's coefficient tile, behind it the exact tier's area.  f32 output is staged
     // through an 8-row x 2 KiB strip (16 KiB, coalesced 1 KiB stores) laid over both once they are dead; the
@@ -243,7 +278,7 @@ __global__ __launch_bounds__(64) JPEGX_INV_OCC void k_inverse_fused(const int16_
     __syncthreads();
 
     float v[64];
-    float A1 = 0.f, A2 = 0.f;   // abs sums of the first-row/column AC terms and of the 49 inner terms
+    float A = 0.f;   // weighted absolute sum of the dequantised coefficients: the error bound's only input (jpegx_math.h)
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
         const uint4 q = *reinterpret_cast<const uint4 *>(lds + tile_off(lane, c));
@@ -257,12 +292,15 @@ __global__ __launch_bounds__(64) JPEGX_INV_OCC void k_inverse_fused(const int16_
                 const int z = h ? ((int)w[s] >> 16) : (int)(short)(w[s] & 0xFFFFu);
                 const float d = (float)z * prm.rq32[n];  // quantizers.py:8-9,30-31,51-53
                 v[n] = d;
-                if (n == 0) continue;
-                if (n < 8 || (n & 7) == 0) A1 += fabsf(d); else A2 += fabsf(d);
+                A = fmaf(fabsf(d), jpegx_inv_weight(n, 0), A);
             }
         }
     }
-    const float E = jpegx_inv_err_bound(fabsf(v[0]), A1, A2, prm.mode == JPEGX_QM_DIVIDE ? 2.f : 0.f);
+    if (prm.mode == JPEGX_QM_DIVIDE) {   // wave-uniform: the fp32 dequantisation rounded twice (divisor, product)
+#pragma unroll
+        for (int n = 0; n < 64; ++n) A = fmaf(fabsf(v[n]), jpegx_inv_weight(n, 2) - jpegx_inv_weight(n, 0), A);
+    }
+    const float E = jpegx_inv_err_from_weighted_sum(A);
     jpegx_idct8x8_f32(v);
 
     // np.round of basis_change.py:43 and, per row, the distance of the worst sample to its integer
@@ -279,7 +317,7 @@ __global__ __launch_bounds__(64) JPEGX_INV_OCC void k_inverse_fused(const int16_
             // re-derives the byte from it with a rounding conversion): 64 extra VGPRs
             asm volatile("" : "+v"(v[r * 8 + c]));
         }
-        rowmask |= (worst + E < 0.5f) ? 0u : (1u << r);
+        rowmask |= (worst + E < JPEGX_SAFE_HALF) ? 0u : (1u << r);
     }
     if (!valid) rowmask = 0;
     const unsigned long long flagged = __ballot(rowmask != 0);
@@ -336,7 +374,7 @@ __global__ __launch_bounds__(64) JPEGX_INV_OCC void k_inverse_fused(const int16_
     const int by = g / wb, bx = g - by * wb;
     void *base = (OUT == 1)
         ? static_cast<void *>(reinterpret_cast<int16_t *>(outv) + (size_t)by * 8 * opitch + (size_t)bx * 8)
-        : static_cast<void *>(reinterpret_cast<unsigned char *>(outv) + (size_t)by * 8 * INF * opitch + (size_t)bx * 8 * INF);
+        : static_cast<void *>(reinterpret_cast<unsigned char *>(outv) + (size_t)by * 8 * (INF ? INF : rep) * opitch + (size_t)bx * 8 * (INF ? INF : rep));
     // the narrow types store straight from the registers: a lane skips the fast-tier row its exact row
     // replaces and stores that one afterwards (every byte is written once; predicated stores, no selects)
 #pragma unroll
@@ -344,9 +382,9 @@ __global__ __launch_bounds__(64) JPEGX_INV_OCC void k_inverse_fused(const int16_
         float x[8];
 #pragma unroll
         for (int c = 0; c < 8; ++c) x[c] = v[r * 8 + c];
-        if (r != fixrow) store_row<OUT, NT, INF>(base, opitch, r, x, clamp);
+        if (r != fixrow) store_row<OUT, NT, INF>(base, opitch, r, x, clamp, rep);
     }
-    if (fixrow >= 0) store_row<OUT, NT, INF>(base, opitch, fixrow, fix, clamp);
+    if (fixrow >= 0) store_row<OUT, NT, INF>(base, opitch, fixrow, fix, clamp, rep);
 }
 }  // namespace
 
@@ -360,8 +398,9 @@ static int inverse_common(const int16_t *d_in, int H, int W, int mode, double pa
     if (out_pitch < (ptrdiff_t)W * inflate) return fail(JPEGX_E_INVALID, "output pitch smaller than the inflated width");
     const int esz = out_type == JPEGX_OUT_F32 ? 4 : (out_type == JPEGX_OUT_I16 ? 2 : 1);
     if (out_type < 0 || out_type > 2) return fail(JPEGX_E_INVALID, "unknown output type");
-    if (((size_t)out_pitch * esz) % ((esz == 1 && inflate == 1) ? 8 : 16) != 0 || !aligned16(d_in) || !aligned16(d_out))
-        return fail(JPEGX_E_INVALID, "inverse: output rows must stay 16-byte (plain u8: 8-byte) aligned");
+    const bool pieces8 = esz == 1 && inflate != 2 && inflate != 4;      // plain u8 and the run-time factor store 8-byte pieces
+    if (((size_t)out_pitch * esz) % (pieces8 ? 8 : 16) != 0 || !aligned16(d_in) || !aligned16(d_out))
+        return fail(JPEGX_E_INVALID, "inverse: output rows must stay 16-byte (u8 with block_size other than 2, 4: 8-byte) aligned");
     QuantParams qp;
     rc = fill_inverse_params(mode, param, &qp);
     if (rc) return rc;
@@ -373,13 +412,14 @@ static int inverse_common(const int16_t *d_in, int H, int W, int mode, double pa
     hipStream_t st = (hipStream_t)stream;
     const bool nt = (flags & JPEGX_F_TUNE_NO_NT) == 0;
 #define JPEGX_LAUNCH_INV(OUT, NT, CL, INF) \
-    hipLaunchKernelGGL((k_inverse_fused<OUT, NT, INF>), grid, block, 0, st, d_in, wb, nblk, qp, CL, d_out, (size_t)out_pitch, g_counters)
+    hipLaunchKernelGGL((k_inverse_fused<OUT, NT, INF>), grid, block, 0, st, d_in, wb, nblk, qp, CL, d_out, (size_t)out_pitch, g_counters, inflate)
 #define JPEGX_LAUNCH_INV_NT(OUT, CL, INF) do { if (nt) JPEGX_LAUNCH_INV(OUT, true, CL, INF); else JPEGX_LAUNCH_INV(OUT, false, CL, INF); } while (0)
     if (out_type == JPEGX_OUT_F32) JPEGX_LAUNCH_INV_NT(0, clamp, 1);
     else if (out_type == JPEGX_OUT_I16) JPEGX_LAUNCH_INV_NT(1, clamp, 1);
     else if (inflate == 1) JPEGX_LAUNCH_INV_NT(2, 1, 1);
     else if (inflate == 2) JPEGX_LAUNCH_INV_NT(2, 1, 2);
-    else JPEGX_LAUNCH_INV_NT(2, 1, 4);
+    else if (inflate == 4) JPEGX_LAUNCH_INV_NT(2, 1, 4);
+    else JPEGX_LAUNCH_INV_NT(2, 1, 0);            // any other block_size: replication factor at run time
 #undef JPEGX_LAUNCH_INV_NT
 #undef JPEGX_LAUNCH_INV
     HIP_TRY(hipGetLastError());
@@ -395,7 +435,7 @@ int jpegx_inverse_fused(const int16_t *d_in, int H, int W, int mode, double para
 int jpegx_inverse_fused_u8_inflated(const int16_t *d_in, int H, int W, int mode, double param, unsigned flags, int bs,
                                     uint8_t *d_out, ptrdiff_t out_pitch, jpegx_stream_t stream)
 {
-    if (bs != 1 && bs != 2 && bs != 4) return fail(JPEGX_E_UNSUPPORTED, "fused inflate supports block_size 1, 2 and 4");
+    if (bs < 1 || bs > 255) return fail(JPEGX_E_UNSUPPORTED, "fused inflate supports block_size 1..255");
     return inverse_common(d_in, H, W, mode, param, flags, d_out, out_pitch, JPEGX_OUT_U8, bs, stream);
 }
 int jpegx_host_inverse_fused_u8_inflated(const int16_t *h_in, int H, int W, int mode, double param, unsigned flags, int bs,

@@ -140,6 +140,31 @@ constexpr int jpegx_fwd_roundings(int n, bool pixel_input)   // n = k * 8 + l
 }
 JPEGX_HD float jpegx_fwd_err_unit(float S) { return S * 0x1.004p-24f; }   // u S (1 + 2^-10)
 
+// Fast-tier quantiser (round 3): round-half-even of the EXACT product v * rq by the magic-constant addition
+//   m = fma(v, rq, 1.5 * 2^23)      one rounding, at integer granularity: m = magic + rint(v * rq) for |v rq| < 2^22
+//   r = m - magic                   exact
+//   d = fma(v, rq, -r)              the distance to that integer, one rounding (relative 2^-24)
+// instead of t = v * rq; r = rint(t); t - r: no v_rndne, no v_cvt_i32 (both issue at 2/3 of the fma rate on
+// gfx950, profiles/r03_valu_rate.txt), and the int16 is the low half of m's bit pattern (two's complement), so two
+// coefficients pack with one byte permute.  The product's own rounding of the old form is gone, the bound
+// F(k, l) u S |rq| stays (it still charges that rounding): a coefficient is safe iff |d| + bound < JPEGX_SAFE_HALF,
+// which leaves 2^-23 for d's rounding; then rint(t64) = r whatever the magnitude (for |v rq| >= 2^22, where m is no
+// longer integer-grained on the negative side, every surviving r is beyond the int16 range and saturates).
+#define JPEGX_RMAGIC 12582912.0f          /* 1.5 * 2^23 */
+#define JPEGX_SAFE_HALF 0.49999988f       /* 0.5 - 2^-23 */
+// `magic` = JPEGX_RMAGIC, handed in by the caller: the kernels keep it in ONE register the optimiser cannot see
+// through -- as a literal it is re-materialised in front of every fma (v_mov + v_fmac instead of one v_fma)
+JPEGX_HD float jpegx_quant_fast_m(float v, float rq, float magic, float &d)
+{
+    const float m = fmaf(v, rq, magic);
+    const float r = m - magic;
+    d = fmaf(v, rq, -r);
+    return m;
+}
+JPEGX_HD float jpegx_quant_fast(float v, float rq, float &d) { return jpegx_quant_fast_m(v, rq, JPEGX_RMAGIC, d); }
+// the quantised integer held by m (valid while |r| < 2^22)
+JPEGX_HD int jpegx_quant_fast_int(float m) { return (int)(m - JPEGX_RMAGIC); }
+
 // Same for the inverse.  A 1-D inverse pass (jpegx_idct8_f32) scales its k = 0 input by exactly 1/8 (a
 // power of two; that term only meets the 3 roundings of the final additions) and every k >= 1 input by
 // c/4 with |c| <= 1 (<= 6 roundings on its path: the fp32 rounding of the constant, the product, three
@@ -158,6 +183,26 @@ JPEGX_HD float jpegx_inv_err_bound(float D, float A1, float A2, float dq)
     const float cD = fmaf(dq, 1.0f / 64, 3.0f / 32), c1 = fmaf(dq, 1.0f / 32, 9.0f / 32), c2 = fmaf(dq, 1.0f / 16, 3.0f / 4);
     return u * fmaf(D, cD, fmaf(A1, c1, A2 * c2));
 }
+
+// The same per input index (round 3).  Roundings on the path from input k of jpegx_idct8_f32 to any of its outputs
+// (the fp32 rounding of the constant, the product, the fma's it passes, the additions g, E and the final one):
+//   k = 0: 3 (x0 / 8 is exact)   k = 4: 5   k = 2: 5   k = 6: 4   k = 1: 6   k = 3: 5   k = 5: 4   k = 7: 3
+// -- the later an input enters a fma chain, the fewer roundings see it.  With s_0 = 1/8 and s_k = 1/4 the share of
+// coefficient Z[k][l] (column pass index k, then row pass index l) in |x32 - x64| is at most
+//   |d_kl| s_k s_l (n_k + n_l + dq) u,      d = the dequantised coefficient, dq as above,
+// so the bound is ONE weighted absolute sum, accumulated with one fma per coefficient where the three-class form
+// used one add: same instruction count, 24 % smaller on average over the 49 inner terms (n_k + n_l averages 9.1
+// instead of 12), hence fewer rows for the float64 tier.
+constexpr int jpegx_idct8_roundings(int k)
+{
+    return k == 0 ? 3 : (k == 1 ? 6 : ((k == 2 || k == 3 || k == 4) ? 5 : ((k == 5 || k == 6) ? 4 : 3)));
+}
+constexpr float jpegx_inv_weight(int n, int dq)   // n = k * 8 + l
+{
+    return ((n >> 3) == 0 ? 0.125f : 0.25f) * ((n & 7) == 0 ? 0.125f : 0.25f) *
+           (float)(jpegx_idct8_roundings(n >> 3) + jpegx_idct8_roundings(n & 7) + dq);
+}
+JPEGX_HD float jpegx_inv_err_from_weighted_sum(float A) { return A * 0x1.004p-24f; }   // u (1 + 2^-10) A
 
 // ---------------------------------------------------------------------------------------------
 // fp64 exact tier (reference operation order)

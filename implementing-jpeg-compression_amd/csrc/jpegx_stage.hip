@@ -136,9 +136,57 @@ int zigzag_common(const void *d_in, int H, int W, ptrdiff_t pitch, int elem_size
     return JPEGX_OK;
 }
 
+// np.dstack of Jpeg.decompress (pipeline/__init__.py:119-122) on the device: `nb` uint8 planes [rows][pitch] ->
+// pixel-interleaved [rows][cols][nb].  One thread = four pixels of one row: a dword from every plane, 4 * nb
+// bytes out (whole dwords when the packed rows keep them aligned).
+struct InterleaveArgs { const unsigned char *plane[JPEGX_MAX_IMAGE_BANDS]; };
+
+__global__ __launch_bounds__(256) void k_interleave_u8(InterleaveArgs a, int nb, int rows, int cols, size_t pitch,
+                                                       unsigned char *__restrict__ out, size_t out_pitch)
+{
+    const int x4 = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    const int x = x4 * 4;
+    if (x >= cols || y >= rows) return;
+    unsigned w[JPEGX_MAX_IMAGE_BANDS];
+#pragma unroll
+    for (int k = 0; k < JPEGX_MAX_IMAGE_BANDS; ++k)
+        w[k] = k < nb ? *reinterpret_cast<const unsigned *>(a.plane[k] + (size_t)y * pitch + x) : 0u;   // pitch is a multiple of 16
+    unsigned char *o = out + (size_t)y * out_pitch + (size_t)x * nb;
+    const int npx = min(4, cols - x);
+    if (nb == 3 && npx == 4 && (out_pitch & 3) == 0) {
+        const unsigned b0 = w[0], b1 = w[1], b2 = w[2];
+        unsigned *o4 = reinterpret_cast<unsigned *>(o);
+        o4[0] = (b0 & 0xFFu) | ((b1 & 0xFFu) << 8) | ((b2 & 0xFFu) << 16) | ((b0 & 0xFF00u) << 16);
+        o4[1] = ((b1 >> 8) & 0xFFu) | (((b2 >> 8) & 0xFFu) << 8) | (b0 & 0xFF0000u) | ((b1 & 0xFF0000u) << 8);
+        o4[2] = ((b2 >> 16) & 0xFFu) | ((b0 >> 24) << 8) | ((b1 >> 24) << 16) | (b2 & 0xFF000000u);
+        return;
+    }
+    for (int i = 0; i < npx; ++i)
+        for (int k = 0; k < nb; ++k) o[i * nb + k] = (unsigned char)(w[k] >> (8 * i));
+}
+
 }  // namespace
 
 extern "C" {
+
+int jpegx_interleave_u8(const void *const *d_planes, int nbands, int rows, int cols, ptrdiff_t pitch, uint8_t *d_out,
+                        ptrdiff_t out_pitch, jpegx_stream_t stream)
+{
+    if (!d_planes || !d_out) return fail(JPEGX_E_INVALID, "null device pointer");
+    if (nbands < 1 || nbands > JPEGX_MAX_IMAGE_BANDS || rows <= 0 || cols <= 0 || rows > 65535)
+        return fail(JPEGX_E_INVALID, "interleave: 1..JPEGX_MAX_IMAGE_BANDS planes, 1..65535 rows");
+    if ((pitch % 4) != 0 || pitch < ((cols + 3) & ~3) || out_pitch < (ptrdiff_t)cols * nbands)
+        return fail(JPEGX_E_INVALID, "interleave: plane pitch must be a multiple of 4 covering the row rounded up to 4; packed pitch >= cols * nbands");
+    InterleaveArgs a;
+    for (int k = 0; k < JPEGX_MAX_IMAGE_BANDS; ++k) {
+        a.plane[k] = k < nbands ? static_cast<const unsigned char *>(d_planes[k]) : nullptr;
+        if (k < nbands && (!d_planes[k] || (reinterpret_cast<uintptr_t>(d_planes[k]) & 3u))) return fail(JPEGX_E_INVALID, "interleave: planes must be 4-byte aligned");
+    }
+    const dim3 block(256), grid(((cols + 3) / 4 + 255) / 256, rows);
+    hipLaunchKernelGGL(k_interleave_u8, grid, block, 0, (hipStream_t)stream, a, nbands, rows, cols, (size_t)pitch, d_out, (size_t)out_pitch);
+    HIP_TRY(hipGetLastError());
+    return JPEGX_OK;
+}
 
 int jpegx_generate_plane(float *d_plane, int H, int W, ptrdiff_t pitch, int kind, uint32_t seed, uint32_t plane,
                          int row0, jpegx_stream_t stream)

@@ -24,6 +24,7 @@ MODE_BY_NAME = {"none": Q_NONE, "discard": Q_DISCARD, "divide": Q_DIVIDE, "qtabl
 F_PIXEL_INPUT = 1
 F_CLAMP_U8 = 2
 F_TUNE_F64_LANE_PER_BLOCK = 0x4
+F_TUNE_DIRECT_STORE = 0x8
 F_TUNE_F64_KERNEL = 0x4000
 F_TUNE_NO_F64_KERNEL = 0x8000
 F_TUNE_NO_NT = 0x100
@@ -120,6 +121,9 @@ SIGNATURES = {
     "jpegx_host_decompress_plane": [_vp, _sz, _int, _int, _int, _int, _dbl, _vp, _pd],
     "jpegx_host_decompress_plane_i64": [_vp, _sz, _int, _int, _int, _int, _dbl, _vp, _int, _int],
     "jpegx_host_entropy_decode_gpu": [_vp, _sz, _c.c_longlong, _vp],
+    "jpegx_host_compress_image": [_vp, _int, _int, _int, _int, _pd, _int, _int, _dbl, _vp, _sz, _int, _vp, _vp, _c.POINTER(_sz)],
+    "jpegx_host_decompress_image": [_vp, _c.POINTER(_sz), _int, _int, _int, _int, _int, _dbl, _vp, _pd, _int, _int, _int],
+    "jpegx_interleave_u8": [_vp, _int, _int, _int, _pd, _vp, _pd, _vp],
     "jpegx_entropy_workspace_bytes": [_c.c_longlong],
     "jpegx_entropy_sizes": [_vp, _c.c_longlong, _vp, _vp],
     "jpegx_entropy_total": [_vp, _c.POINTER(_c.c_ulonglong), _vp],
@@ -136,6 +140,14 @@ SIGNATURES = {
     "jpegx_comm_count": [_vp, _c.POINTER(_int)],
     "jpegx_comm_gather_bytes": [_vp, _vp, _sz, _vp, _c.POINTER(_sz), _c.POINTER(_sz), _int, _vp],
 }
+# explicit-device forms (csrc/jpegx_on.cpp): the plain signature behind a leading device index
+for _name in ("jpegx_malloc", "jpegx_free", "jpegx_stream_create", "jpegx_generate_plane", "jpegx_forward_fused_pooled",
+              "jpegx_forward_fused_u8", "jpegx_forward_fused_f64", "jpegx_forward_fused_planes", "jpegx_mean_pool_f64",
+              "jpegx_inverse_fused_u8_inflated", "jpegx_entropy_sizes", "jpegx_entropy_total", "jpegx_entropy_block_sizes",
+              "jpegx_entropy_emit", "jpegx_host_compress_begin", "jpegx_host_compress_image", "jpegx_host_decompress_plane",
+              "jpegx_host_decompress_plane_i64", "jpegx_host_decompress_image", "jpegx_host_entropy_decode_gpu",
+              "jpegx_host_pool_release", "jpegx_comm_create_deadline"):
+    SIGNATURES[_name + "_on"] = [_int] + SIGNATURES[_name]
 RESTYPES = {"jpegx_entropy_workspace_bytes": _sz}   # everything else returns int
 
 
@@ -579,6 +591,73 @@ def compress_plane_native(plane, block_size=1, mode="qtable", param=0.0):
         raise
     check(rc, "jpegx_host_compress_finish")
     return blob
+
+
+ALLOC_FN = ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t)   # jpegx_alloc_fn
+
+
+def compress_image_native(planes, block_size=1, mode="qtable", param=0.0, prefix=None):
+    """Steps 1-8 for all bands of one picture in ONE native job (jpegx_host_compress_image): the bands share one lock
+    of the device's pool and alternate between two streams; once all byte counts are known libjpegx asks (through a
+    callback) for ONE ``bytes`` object and copies every band from the device straight to its place in it.
+    ``planes``: 2-D arrays of one shape and dtype (uint8 / int32 / int64), already padded to a multiple of
+    8 * block_size.  With ``prefix`` (the container header) the result is the finished file -- prefix, then every
+    band behind its '<L' byte count (file_format.generate_data); without it the list of the bands' byte strings.
+    None when the bands are not 8-bit planes in a layout this path takes."""
+    arrs = [p if isinstance(p, np.ndarray) else np.asarray(p) for p in planes]
+    bs = int(block_size)
+    if not arrs or len(arrs) > 4:
+        return None
+    a0 = arrs[0]
+    elem = _ELEM_OF.get(a0.dtype)
+    if elem is None or a0.ndim != 2:
+        return None
+    if any(a.shape != a0.shape or a.dtype != a0.dtype or not a.flags.c_contiguous for a in arrs):
+        return None
+    hh, ww = a0.shape
+    if hh == 0 or hh % (8 * bs) or ww % (8 * bs) or not 1 <= bs <= 255:
+        return None
+    if bs in (1, 2, 4) and (ww % 16 or not u8_path_ok(ww // bs, bs, ww, mode, param)):
+        return None
+    L = lib()
+    box = []
+
+    def alloc(_user, nbytes):
+        blob = _pyapi.PyBytes_FromStringAndSize(None, nbytes)       # uninitialised bytes, filled by the device copies
+        box.append(blob)
+        return _pyapi.PyBytes_AsString(blob)
+    cb = ALLOC_FN(alloc)
+    ptrs = (ctypes.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+    sizes = (ctypes.c_size_t * len(arrs))()
+    head = bytes(prefix) if prefix is not None else b""
+    rc = L.jpegx_host_compress_image(ptrs, len(arrs), elem, hh // bs, ww // bs, ww, bs, mode_of(mode), float(param),
+                                     head, len(head), 1 if prefix is not None else 0, cb, None, sizes)
+    if rc == -4:                                        # JPEGX_E_UNSUPPORTED: not 8-bit bands after all
+        return None
+    check(rc, "jpegx_host_compress_image")
+    whole = box[0]
+    if prefix is not None:
+        return whole
+    out, at = [], 0
+    for n in sizes:
+        out.append(whole[at:at + n])
+        at += n
+    return out
+
+
+def decompress_image_native(blobs, height, width, block_size, mode, param, rows, cols, interleave=True):
+    """All bands of one picture back in ONE native job (jpegx_host_decompress_image).  (height, width): a band after
+    pooling (multiples of 8); the result is cropped to (rows, cols): uint8 (rows, cols, nbands) when ``interleave``
+    (what PIL's Image.fromarray takes), else (nbands, rows, cols)."""
+    bufs = [np.frombuffer(bytes(b), dtype=np.uint8) for b in blobs]
+    n = len(bufs)
+    ptrs = (ctypes.c_void_p * n)(*[b.ctypes.data if b.size else None for b in bufs])
+    sizes = (ctypes.c_size_t * n)(*[b.size for b in bufs])
+    out = np.empty((rows, cols, n) if interleave else (n, rows, cols), dtype=np.uint8)
+    check(lib().jpegx_host_decompress_image(ptrs, sizes, n, int(height), int(width), int(block_size), mode_of(mode), float(param),
+                                            out.ctypes.data, cols * n if interleave else cols, int(rows), int(cols), 1 if interleave else 0),
+          "jpegx_host_decompress_image")
+    return out
 
 
 def compress_plane(plane, block_size=1, mode="qtable", param=0.0):

@@ -112,7 +112,7 @@ def _hot_forward(pre, config):
     pre = pre.astype(np.float64)
     if pre.shape[1] % 2 == 0:
         zz = jpegx.forward_fused_f64(pre, mode, param)          # one all-float64 launch
-        if np.abs(zz).max() < 32767:                            # int16 saturation would hide larger values
+        if zz.min() > -32768 and zz.max() < 32767:              # int16 saturation would hide larger values (np.abs wraps at -32768)
             return zz.astype(np.float64)
     coeffs = jpegx.quantize_f64(jpegx.dct8x8_f64(pre), mode, param)
     return jpegx.zigzag(coeffs)
@@ -157,6 +157,8 @@ def _bad_rle(exc):
     import util
     if "BadRleCodeError" in str(exc):
         return util.BadRleCodeError(str(exc))
+    if "ValueError" in str(exc):                    # what the reference raises for these streams (int('', 2) / reshape)
+        return ValueError(str(exc))
     return exc
 
 
@@ -204,7 +206,7 @@ def _back_end_fused(zz, config):
     bs = config.block_size
     zz = np.asarray(zz)
     mode, param = config.quantization.gpu_mode()
-    if bs not in (1, 2, 4) or zz.ndim != 3 or zz.shape[2] != 64 or zz.size == 0:
+    if not 1 <= bs <= 255 or zz.ndim != 3 or zz.shape[2] != 64 or zz.size == 0:
         return None
     if mode == "divide" and abs(param) * 32767 >= 2 ** 24:
         return None
@@ -247,7 +249,7 @@ def decompress_band_u8(compression_result, config):
     import jpegx
     a = compression_result
     if _accelerated(config) and _stock_registry() and isinstance(a, (bytes, bytearray)) and len(a) \
-            and config.block_size in (1, 2, 4):
+            and 1 <= config.block_size <= 255:
         mode, param = config.quantization.gpu_mode()
         if not (mode == "divide" and abs(param) * 32767 >= 2 ** 24):
             rle = run_length_encoding.RunLengthEncoding(config)
@@ -271,7 +273,7 @@ def decompress_band(compression_result, config):
                 rle = run_length_encoding.RunLengthEncoding(config)
                 hb, wb = rle._height_in_blocks(), rle._width_in_blocks()
                 mode, param = config.quantization.gpu_mode()
-                if config.block_size in (1, 2, 4) and len(a) and not (mode == "divide" and abs(param) * 32767 >= 2 ** 24):
+                if 1 <= config.block_size <= 255 and len(a) and not (mode == "divide" and abs(param) * 32767 >= 2 ** 24):
                     # all nine steps inverted on the device, entropy decoding included; only the samples come back
                     try:
                         band = jpegx.decompress_plane_i64(a, hb * 8, wb * 8, config.block_size, mode, param,
@@ -316,7 +318,11 @@ class Jpeg:
         self.config = config
 
     def compress(self, image):
-        bands = [compress_band(band_to_array(band), self.config) for band in image.split()]
+        arrays = [band_to_array(band) for band in image.split()]
+        whole = _compress_image(arrays, self.config)        # the finished container, written band by band from the device
+        if whole is not None:
+            return whole
+        bands = [compress_band(a, self.config) for a in arrays]
         return file_format.generate_data(self.config, CompressedData(*bands))
 
     @staticmethod
@@ -324,5 +330,48 @@ class Jpeg:
         from PIL import Image
         config, data = file_format.read_data(bytestream)
         size = (config.height, config.width)
-        planes = [decompress_band_u8(b, config).reshape(size) for b in (data.y, data.cb, data.cr)]
-        return Image.fromarray(np.dstack(planes), mode="YCbCr")
+        packed = _decompress_image((data.y, data.cb, data.cr), config)
+        if packed is None:
+            packed = np.dstack([decompress_band_u8(b, config).reshape(size) for b in (data.y, data.cb, data.cr)])
+        return Image.fromarray(packed, mode="YCbCr")
+
+
+def _compress_image(arrays, config):
+    """The three bands of one picture through ONE native job (jpegx_host_compress_image) that writes the finished
+    container: the bytes of file_format.generate_data over three compress_band calls (pipeline/__init__.py:102-110,
+    file_format.py:86-93), with the bands alternating between two streams and no concatenation on the host.
+    None when the configuration or the bands do not take that road."""
+    import jpegx
+    if not (_accelerated(config) and _stock_registry()):
+        return None
+    bs = config.block_size
+    if not 1 <= bs <= 255 or any(a.ndim != 2 or a.size == 0 or a.dtype.kind not in "ui" for a in arrays):
+        return None
+    mode, param = config.quantization.gpu_mode()
+    padded = [np.ascontiguousarray(a if bs == 1 else padding.Padding(config).execute(a)) for a in arrays]
+    if any(p.shape[0] % (8 * bs) or p.shape[1] % (8 * bs) for p in padded):
+        return None                                         # DCT padding needed: the per-band road pools on the host first
+    try:
+        return jpegx.compress_image_native(padded, bs, mode, param, prefix=file_format.create_header(config))
+    except jpegx.JpegxError as exc:
+        raise _bad_rle(exc)
+
+
+def _decompress_image(blobs, config):
+    """Jpeg.decompress's three decompress_band calls + np.dstack (pipeline/__init__.py:112-124) as ONE native job;
+    (height, width, 3) uint8, or None when this road does not apply or the device decoder refuses a stream (the
+    per-band road then names the fault)."""
+    import jpegx
+    if not (_accelerated(config) and _stock_registry() and 1 <= config.block_size <= 255):
+        return None
+    if any(not isinstance(b, (bytes, bytearray)) or not len(b) for b in blobs):
+        return None
+    mode, param = config.quantization.gpu_mode()
+    if mode == "divide" and abs(param) * 32767 >= 2 ** 24:
+        return None
+    rle = run_length_encoding.RunLengthEncoding(config)
+    hb, wb = rle._height_in_blocks(), rle._width_in_blocks()
+    try:
+        return jpegx.decompress_image_native(blobs, hb * 8, wb * 8, config.block_size, mode, param, config.height, config.width)
+    except jpegx.JpegxError:
+        return None

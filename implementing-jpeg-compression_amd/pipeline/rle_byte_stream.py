@@ -88,8 +88,8 @@ class RleBytestream(AlgorithmStep):
             elif run == 15 and size == 0:
                 out.append((15, 0, 0))
             else:
-                if size == 0:                       # the reference fails here too: int('', base=2)
-                    raise ValueError("run-length code ({}, 0) has no amplitude bits".format(run))
+                if size <= 1:                       # the reference fails here too: int('', base=2) (no amplitude bits)
+                    raise ValueError("run-length code ({}, {}) has no amplitude bits".format(run, size))
                 bits = take(size)
                 magnitude = bits & ((1 << (size - 1)) - 1)
                 out.append((run, size, magnitude if bits >> (size - 1) else -magnitude))

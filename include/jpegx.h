@@ -72,6 +72,7 @@ typedef enum jpegx_quant_mode {
 #define JPEGX_F_TUNE_NO_XCD_CONTIG 0x20000u /* never: plain round-robin order */
 #define JPEGX_F_TUNE_COLUMN_UNITS 0x40000u    /* forward: force the strip kernel with the column-wise exact tier     */
 #define JPEGX_F_TUNE_NO_COLUMN_UNITS 0x80000u /* forward: never pick it                                              */
+#define JPEGX_F_TUNE_DIRECT_STORE 0x8u /* uint8 forward: per-lane 16-byte stores instead of the LDS output tile (A/B) */
 #define JPEGX_F_TUNE_NO_STRIP 0x200u /* forward: per-lane global loads instead of LDS-DMA staging    */
 
 /* output element type of jpegx_inverse_fused */
@@ -178,8 +179,9 @@ int jpegx_inverse_fused(const int16_t *d_in, int H, int W, int mode, double para
 
 /* The two hot entries with an explicit device index ("every entry takes a device index and
  * an optional stream handle"): the pointers and the stream must belong to `device`; the calling thread's
- * current device is left as it was.  Every other entry works on the thread's current device
- * (jpegx_set_device), which is what a one-process-per-GPU job sets once at start.                       */
+ * current device is left as it was.  The other data-path entries have the same form further down
+ * (jpegx_<name>_on); the plain forms work on the thread's current device (jpegx_set_device), which is what a
+ * one-process-per-GPU job sets once at start.                                                               */
 int jpegx_forward_fused_on(int device, const float *d_in, int H, int W, ptrdiff_t pitch, int mode, double param,
                            unsigned flags, int16_t *d_out, jpegx_stream_t stream);
 int jpegx_inverse_fused_on(int device, const int16_t *d_in, int H, int W, int mode, double param, unsigned flags,
@@ -187,7 +189,8 @@ int jpegx_inverse_fused_on(int device, const int16_t *d_in, int H, int W, int mo
 
 /* Inverse straight to displayable samples: uint8 with the clamp of pipeline/normalization.py:10-14
  * AND SubSampling.invert (pipeline/subsampling.py:13-14 -> util.inflate, util.py:6-14) fused:
- * every sample is replicated bs x bs times (bs in {1,2,4}); d_out is [H*bs][out_pitch >= W*bs]. */
+ * every sample is replicated bs x bs times, bs in 1..255 (1, 2, 4: compile-time forms; any other factor is a
+ * run-time argument of the same kernel); d_out is [H*bs][out_pitch >= W*bs], rows 8-byte aligned (bs 2, 4: 16). */
 int jpegx_inverse_fused_u8_inflated(const int16_t *d_in, int H, int W, int mode, double param,
                                     unsigned flags, int bs, uint8_t *d_out, ptrdiff_t out_pitch,
                                     jpegx_stream_t stream);
@@ -296,7 +299,9 @@ int jpegx_host_idct8x8_f32(const float *h_in, int H, int W, float *h_out);
  * JPEGX_E_UNSUPPORTED) and narrowed by a few host threads.  _begin uploads, runs steps 1+4+5+6 (fused) and
  * 7+8 (device entropy stage) on the device's pooled stream and buffers, and reports the size of the byte
  * stream; _finish copies it into h_out (>= that many bytes).  Between the two calls the device's pool is
- * held by the calling thread; _abort gives it back without copying.  bs 1, 2, 4: the uint8 kernels with
+ * held by the calling thread (any other pooled entry -- a second _begin, the host conveniences, _decompress_*,
+ * _pool_release -- returns JPEGX_E_INVALID on that thread until then; other threads wait); _finish / _abort act on
+ * the job the thread opened, whatever its current device has become; _abort gives the pool back without copying.  bs 1, 2, 4: the uint8 kernels with
  * the mean folded in (W*bs a multiple of 16); any other bs: jpegx_mean_pool_f64 + jpegx_forward_fused_f64. */
 int jpegx_host_compress_begin(const void *h_plane, int elem_size, int H, int W, ptrdiff_t pitch, int bs,
                               int mode, double param, size_t *nbytes);
@@ -314,10 +319,80 @@ int jpegx_host_decompress_plane(const uint8_t *h_bytes, size_t nbytes, int H, in
  * rows <= H*bs, cols <= W*bs): samples staged in pinned memory and widened by a few host threads          */
 int jpegx_host_decompress_plane_i64(const uint8_t *h_bytes, size_t nbytes, int H, int W, int bs, int mode,
                                     double param, int64_t *h_out, int rows, int cols);
+/* ---- whole image in one native job (Jpeg.compress / Jpeg.decompress, pipeline/__init__.py:102-124: Y, Cb, Cr
+ * through compress_band / decompress_band one after another) -------------------------------------------------
+ * The bands of one picture go through ONE lock of the device's pool on two alternating streams: the upload and
+ * transform of band k + 1 overlap the entropy stage and the download of band k.  All bands share shape, block_size
+ * and quantiser (the reference applies one Configuration to the three bands).
+ * compress_image: once every band's byte count is known, `alloc(user, total)` is called ONCE (on the calling
+ * thread) for the destination of the whole result -- e.g. a fresh bytes object of exactly that size -- laid out as
+ * [prefix][u32 LE count][band 0][u32 LE count][band 1] ... (the counts only with length_prefixes != 0): with the
+ * container header as prefix that is the reference's file (file_format.py:86-93), nothing is concatenated on the
+ * host.  Fresh destination pages are touched by a few host threads, then every band is copied from the device
+ * straight to its place.  nbytes[k] = the bands' byte counts.
+ * decompress_image: uint8 samples cropped to rows x cols, either as planes stacked behind each other
+ * ([band][rows][out_pitch], interleave = 0) or pixel-interleaved ([rows][cols][nbands], rows out_pitch bytes
+ * apart, interleave = 1: the np.dstack of pipeline/__init__.py:121 done on the device).                         */
+#define JPEGX_MAX_IMAGE_BANDS 4
+typedef void *(*jpegx_alloc_fn)(void *user, size_t nbytes);
+int jpegx_host_compress_image(const void *const *h_planes, int nbands, int elem_size, int H, int W, ptrdiff_t pitch,
+                              int bs, int mode, double param, const void *prefix, size_t prefix_len,
+                              int length_prefixes, jpegx_alloc_fn alloc, void *user, size_t *nbytes);
+int jpegx_host_decompress_image(const uint8_t *const *h_bytes, const size_t *nbytes, int nbands, int H, int W, int bs,
+                                int mode, double param, uint8_t *h_out, ptrdiff_t out_pitch, int rows, int cols,
+                                int interleave);
+/* device planes [rows][pitch] (uint8, pitch a multiple of 4) -> pixel-interleaved [rows][cols][nbands] */
+int jpegx_interleave_u8(const void *const *d_planes, int nbands, int rows, int cols, ptrdiff_t pitch, uint8_t *d_out,
+                        ptrdiff_t out_pitch, jpegx_stream_t stream);
 /* the entropy decoding alone on the device: bytes -> int16 [nblocks][64] (= jpegx_host_entropy_decode) */
 int jpegx_host_entropy_decode_gpu(const uint8_t *h_bytes, size_t nbytes, long long nblocks, int16_t *h_zz);
 /* frees the pooled device / pinned buffers and the pooled stream of the current device */
 int jpegx_host_pool_release(void);
+
+/* ---- explicit-device forms: jpegx_<name>_on(device, ...) == jpegx_<name>(...) with `device` made current for the
+ * call and the thread's own current device restored afterwards (csrc/jpegx_on.cpp).  With them one host thread
+ * can drive every GPU of a node; device pointers and streams handed in must belong to `device`.
+ * jpegx_host_compress_finish / _abort need no such form: they act on the job the calling thread opened. --------- */
+int jpegx_malloc_on(int device, void **dptr, size_t bytes);
+int jpegx_free_on(int device, void *dptr);
+int jpegx_stream_create_on(int device, jpegx_stream_t *stream);
+int jpegx_generate_plane_on(int device, float *d_plane, int H, int W, ptrdiff_t pitch, int kind, uint32_t seed,
+                            uint32_t plane, int row0, jpegx_stream_t stream);
+int jpegx_forward_fused_pooled_on(int device, const float *d_in, int H, int W, ptrdiff_t pitch, int bs, int mode,
+                                  double param, unsigned flags, int16_t *d_out, jpegx_stream_t stream);
+int jpegx_forward_fused_u8_on(int device, const uint8_t *d_in, int H, int W, ptrdiff_t pitch, int bs, int mode,
+                              double param, unsigned flags, int16_t *d_out, jpegx_stream_t stream);
+int jpegx_forward_fused_f64_on(int device, const double *d_in, int H, int W, ptrdiff_t pitch, int mode, double param,
+                               unsigned flags, int16_t *d_out, jpegx_stream_t stream);
+int jpegx_forward_fused_planes_on(int device, const jpegx_plane_desc *planes, int nplanes, int mode, double param,
+                                  unsigned flags, jpegx_stream_t stream);
+int jpegx_mean_pool_f64_on(int device, const void *d_in, int elem_size, int H, int W, ptrdiff_t pitch, int bs,
+                           double *d_out, ptrdiff_t out_pitch, jpegx_stream_t stream);
+int jpegx_inverse_fused_u8_inflated_on(int device, const int16_t *d_in, int H, int W, int mode, double param,
+                                       unsigned flags, int bs, uint8_t *d_out, ptrdiff_t out_pitch,
+                                       jpegx_stream_t stream);
+int jpegx_entropy_sizes_on(int device, const int16_t *d_zz, long long nblocks, void *d_workspace, jpegx_stream_t stream);
+int jpegx_entropy_total_on(int device, const void *d_workspace, unsigned long long *h_total, jpegx_stream_t stream);
+int jpegx_entropy_block_sizes_on(int device, const void *d_workspace, long long nblocks, uint32_t *h_sizes,
+                                 jpegx_stream_t stream);
+int jpegx_entropy_emit_on(int device, const int16_t *d_zz, long long nblocks, const void *d_workspace, uint8_t *d_out,
+                          jpegx_stream_t stream);
+int jpegx_host_compress_begin_on(int device, const void *h_plane, int elem_size, int H, int W, ptrdiff_t pitch, int bs,
+                                 int mode, double param, size_t *nbytes);
+int jpegx_host_compress_image_on(int device, const void *const *h_planes, int nbands, int elem_size, int H, int W,
+                                 ptrdiff_t pitch, int bs, int mode, double param, const void *prefix, size_t prefix_len,
+                                 int length_prefixes, jpegx_alloc_fn alloc, void *user, size_t *nbytes);
+int jpegx_host_decompress_plane_on(int device, const uint8_t *h_bytes, size_t nbytes, int H, int W, int bs, int mode,
+                                   double param, uint8_t *h_out, ptrdiff_t out_pitch);
+int jpegx_host_decompress_plane_i64_on(int device, const uint8_t *h_bytes, size_t nbytes, int H, int W, int bs, int mode,
+                                       double param, int64_t *h_out, int rows, int cols);
+int jpegx_host_decompress_image_on(int device, const uint8_t *const *h_bytes, const size_t *nbytes, int nbands, int H,
+                                   int W, int bs, int mode, double param, uint8_t *h_out, ptrdiff_t out_pitch, int rows,
+                                   int cols, int interleave);
+int jpegx_host_entropy_decode_gpu_on(int device, const uint8_t *h_bytes, size_t nbytes, long long nblocks, int16_t *h_zz);
+int jpegx_host_pool_release_on(int device);
+int jpegx_comm_create_deadline_on(int device, jpegx_comm_t *comm, int nranks, int rank, const void *id128,
+                                  double timeout_s);
 
 /* ---- instrumentation ---------------------------------------------------------------------
  * When d_counters is non-NULL the fused kernels atomically add, per launch:

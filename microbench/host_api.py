@@ -42,5 +42,41 @@ def main():
                   "mean abs error %.2f" % (kind, band.dtype, bs, tc * 1e3, nblk / tc / 1e6, len(blob), td * 1e3, tu * 1e3, err), flush=True)
 
 
+def image():
+    """Whole-picture jobs (Jpeg.compress / Jpeg.decompress as ONE native job, jpegx_host_compress_image /
+    _decompress_image) against the same bands one by one, 3 x 4096^2 uint8 bands."""
+    jpegx.require_device()
+    size = 4096
+    for kind in ("smooth", "noise"):
+        for bs in (1, 2):
+            bands = [jpegx.synth.generate_plane(kind, size, size, seed=s, dtype=np.int64).astype(np.uint8) for s in (1, 2, 3)]
+            cfg = pipeline.Configuration(width=size, height=size, block_size=bs, dct_size=8,
+                                         quantization=pipeline.QuantizationMethod("qtable"))
+            mode, param = cfg.quantization.gpu_mode()
+            for _ in range(2):
+                blobs = jpegx.compress_image_native(bands, bs, mode, param)        # warm-up (allocations, clocks)
+                jpegx.decompress_image_native(blobs, size // bs, size // bs, bs, mode, param, size, size)
+            t1, one = best(lambda: pipeline.compress_band(bands[0], cfg), 5)
+            t3s, _ = best(lambda: [pipeline.compress_band(b, cfg) for b in bands], 5)
+            import file_format
+            head = file_format.create_header(cfg)
+            t3, whole = best(lambda: jpegx.compress_image_native(bands, bs, mode, param, prefix=head), 5)
+            t3c, _ = best(lambda: file_format.generate_data(cfg, pipeline.CompressedData(*[pipeline.compress_band(b, cfg) for b in bands])), 5)
+            blobs = jpegx.compress_image_native(bands, bs, mode, param)
+            assert blobs[0] == one and whole == file_format.generate_data(cfg, pipeline.CompressedData(*blobs))
+            d1, _ = best(lambda: pipeline.decompress_band_u8(blobs[0], cfg), 5)
+            d3s, ref = best(lambda: np.dstack([pipeline.decompress_band_u8(b, cfg) for b in blobs]), 5)
+            d3, got = best(lambda: jpegx.decompress_image_native(blobs, size // bs, size // bs, bs, mode, param, size, size), 5)
+            assert np.array_equal(got, ref)
+            up, down = 3 * size * size / 1e6, sum(len(b) for b in blobs) / 1e6
+            print("%-6s block_size %d: compress one band %.2f ms, three band jobs %.2f ms (+ container %.2f ms), ONE image job -> container %.2f ms "
+                  "(%.2f x one band; %.0f MB up, %.1f MB down); "
+                  "decompress one band %.2f ms, three band jobs + dstack %.2f ms, ONE image job %.2f ms (%.2f x one band)"
+                  % (kind, bs, t1 * 1e3, t3s * 1e3, t3c * 1e3, t3 * 1e3, t3 / t1, up, down, d1 * 1e3, d3s * 1e3, d3 * 1e3, d3 / d1), flush=True)
+
+
 if __name__ == "__main__":
-    main()
+    if "--image" in sys.argv:
+        image()
+    else:
+        main()

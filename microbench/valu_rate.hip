@@ -25,6 +25,8 @@ __global__ __launch_bounds__(256) void k_rate(float *out, int iters, float seed)
     const float m = 1.0000001f, c = 1e-9f;
     const float sm = __builtin_amdgcn_readfirstlane(__float_as_int(seed)) ? 1.0000001f : 1.0f;   // lives in an SGPR
     const f32x2 pm = {m, m}, pc = {c, c};
+    double dd[4] = {1.0 + seed, 2.0, 3.0, 4.0};
+    const double dm = 1.0000001, dc = 1e-9;
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -62,12 +64,33 @@ __global__ __launch_bounds__(256) void k_rate(float *out, int iters, float seed)
                 if (OP == 29) asm volatile("v_cvt_f32_i32 %0, %1" : "=v"(f[k]) : "v"(u[k]));
                 if (OP == 30) asm volatile("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(f[k]) : "v"(u[k]));
                 if (OP == 31) asm volatile("v_cvt_u32_f32 %0, %1" : "=v"(u[k]) : "v"(f[k]));
+                if (OP == 32) asm volatile("v_max_f32 %0, %0, %1" : "+v"(f[k]) : "v"(c));
+                if (OP == 33) asm volatile("v_max_f32 %0, |%0|, |%1|" : "+v"(f[k]) : "v"(c));
+                if (OP == 34) asm volatile("v_and_b32 %0, %0, %1" : "+v"(u[k]) : "v"(u[(k + 1) & 7]));
+                if (OP == 35) asm volatile("v_or_b32 %0, %0, %1" : "+v"(u[k]) : "v"(u[(k + 1) & 7]));
+                if (OP == 36) asm volatile("v_lshlrev_b32 %0, 3, %0" : "+v"(u[k]));
+                if (OP == 37) asm volatile("v_add_u32 %0, %0, %1" : "+v"(u[k]) : "v"(u[(k + 1) & 7]));
+                if (OP == 38) asm volatile("v_add_u32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_3" : "+v"(u[k]) : "v"(u[(k + 1) & 7]));
+                if (OP == 39) asm volatile("v_min_u32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "+v"(u[k]) : "v"(u[(k + 1) & 7]));
+                if (OP == 40) asm volatile("v_fract_f32 %0, %0" : "+v"(f[k]));
+                if (OP == 41) asm volatile("v_cvt_f32_u32 %0, %1" : "=v"(f[k]) : "v"(u[k]));
+                if (OP == 42) asm volatile("v_alignbit_b32 %0, %0, %1, 8" : "+v"(u[k]) : "v"(u[(k + 1) & 7]));
+                if (OP == 43) asm volatile("v_pack_b32_f16 %0, %0, %1" : "+v"(u[k]) : "v"(u[(k + 1) & 7]));
+                if (OP == 44) asm volatile("v_bfi_b32 %0, %1, %0, %2" : "+v"(u[k]) : "v"(0xFFFFu), "v"(u[(k + 1) & 7]));
+                if (OP == 45) asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(u[k]) : "v"(0x10101u));
+                if (OP == 46) asm volatile("v_pk_add_u16 %0, %0, %1" : "+v"(u[k]) : "v"(u[(k + 1) & 7]));
+                if (OP == 47) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(u[k]) : "v"(u[(k + 1) & 7]) : "vcc");
+                if (OP == 48) asm volatile("v_cmp_lt_f32 vcc, %0, %1" : : "v"(f[k]), "v"(c) : "vcc");
+                if (OP == 49) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(f[k]) : "v"(m), "v"(c));
+                if (OP == 50) asm volatile("v_cvt_f32_ubyte0_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2" : "=v"(f[k]) : "v"(u[k]));
+                if (OP == 51) asm volatile("v_add_f32 %0, |%0|, %1" : "+v"(f[k]) : "v"(c));
+                if (OP == 52) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(dd[k & 3]) : "v"(dm), "v"(dc));
             }
         }
     }
     float s = 0;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) s += f[k] + p[k].x + p[k].y + (float)u[k];
+    for (int k = 0; k < 8; ++k) s += f[k] + p[k].x + p[k].y + (float)u[k] + (float)dd[k & 3];
     if (s == 12345.678f) out[0] = s;
 }
 
@@ -76,7 +99,10 @@ static const char *NAMES[] = {"v_fma_f32", "v_pk_fma_f32", "v_pk_mul_f32", "v_pk
                               "v_and_or_b32", "v_lshl_or_b32", "v_cvt_pk_i16_i32", "v_cvt_pk_u8_f32", "v_sub_f32", "v_pk_add_f32 neg_lo",
                               "v_pk_fma_f32 op_sel", "v_bfe_u32", "v_mov_b32", "v_fma_f32 (sgpr src)", "v_fmamk_f32 (literal)", "v_mul_f32 (sgpr src)",
                               "v_fma_f32 3 vgpr srcs", "v_fma_f32 1 chain", "v_fma_f32 2 chains", "v_fma_f32 4 chains", "v_cvt_f32_i32",
-                              "v_cvt_f32_i32 sdwa", "v_cvt_u32_f32"};
+                              "v_cvt_f32_i32 sdwa", "v_cvt_u32_f32", "v_max_f32", "v_max_f32 |a| |b|", "v_and_b32", "v_or_b32", "v_lshlrev_b32",
+                              "v_add_u32", "v_add_u32 sdwa bytes", "v_min_u32 sdwa byte", "v_fract_f32", "v_cvt_f32_u32", "v_alignbit_b32",
+                              "v_pack_b32_f16", "v_bfi_b32", "v_mul_u32_u24", "v_pk_add_u16", "v_cndmask_b32", "v_cmp_lt_f32", "v_fmac_f32",
+                              "v_cvt_f32_ubyte0 sdwa", "v_add_f32 |a|", "v_fma_f64 4 chains"};
 
 static double g_base = 0;
 
@@ -116,6 +142,8 @@ int main()
     sweep<4>(d); sweep<5>(d); sweep<17>(d); sweep<6>(d); sweep<7>(d); sweep<8>(d); sweep<9>(d); sweep<10>(d); sweep<11>(d); sweep<12>(d);
     sweep<13>(d); sweep<14>(d); sweep<15>(d); sweep<16>(d); sweep<20>(d); sweep<21>(d);
     sweep<22>(d); sweep<23>(d); sweep<24>(d); sweep<25>(d); sweep<26>(d); sweep<27>(d); sweep<28>(d); sweep<29>(d); sweep<30>(d); sweep<31>(d);
+    sweep<32>(d); sweep<33>(d); sweep<34>(d); sweep<35>(d); sweep<36>(d); sweep<37>(d); sweep<38>(d); sweep<39>(d); sweep<40>(d); sweep<41>(d);
+    sweep<42>(d); sweep<43>(d); sweep<44>(d); sweep<45>(d); sweep<46>(d); sweep<47>(d); sweep<48>(d); sweep<49>(d); sweep<50>(d); sweep<51>(d); sweep<52>(d);
     for (int w : {1, 2, 4}) run<26>(d, w);
     for (int w : {1, 2, 4}) run<28>(d, w);
     for (int w : {1, 2, 3, 4, 6}) run<0>(d, w);

@@ -52,15 +52,18 @@ int emul_forward(const float *in, int H, int W, int mode, double param, const fl
                 int n = T_ZZ[p];
                 if (out_dct32) out_dct32[(size_t)(by * 8 + (n >> 3)) * W + bx * 8 + (n & 7)] = v[n];
                 const int F = jpegx_fwd_roundings(n, pixel_input != 0);
-                /* observed |t32 - t64| against the kernel's bound E F |1/q| (the quantiser's own roundings included) */
-                float t = v[n] * rq32[n];
+                /* observed |v rq - t64| against the kernel's bound E F |1/q| (v rq: the exact product the fast tier
+                   rounds, jpegx_quant_fast; the bound still charges a product rounding that is no longer made) */
+                double t = (double)v[n] * (double)rq32[n];
                 double t64 = mode == JPEGX_QM_QTABLE ? y64[n] * rq64[n] : (mode == JPEGX_QM_DIVIDE ? y64[n] / param : y64[n]);
                 double bound = (double)E * F * fabs((double)rq32[n]);
-                double ratio = bound > 0 ? fabs((double)t - t64) / bound : 0.0;
+                double ratio = bound > 0 ? fabs(t - t64) / bound : 0.0;
                 if (rq32[n] != 0.f && ratio > maxratio) maxratio = ratio;
-                float r = rintf(t);
-                float g = fmaf(E * (float)F, fabsf(rq32[n]), fabsf(t - r));
-                int flag = g >= 0.5f;
+                float d;
+                const float mg = jpegx_quant_fast(v[n], rq32[n], d);
+                const float r = mg - JPEGX_RMAGIC;
+                float g = fmaf(E * (float)F, fabsf(rq32[n]), fabsf(d));
+                int flag = !(g < JPEGX_SAFE_HALF);
                 if (dc_exact && n == 0) flag = 0;
                 int res;
                 if (flag) {
@@ -86,7 +89,7 @@ int emul_inverse(const int16_t *in, int H, int W, int mode, double param, int32_
     for (int by = 0; by < H / 8; ++by)
         for (int bx = 0; bx < wb; ++bx) {
             const int16_t *z = in + ((size_t)by * wb + bx) * 64;
-            float v[64]; double a[64]; float A1 = 0.f, A2 = 0.f;
+            float v[64]; double a[64]; float A = 0.f;
             for (int p = 0; p < 64; ++p) {
                 int n = T_ZZ[p];
                 double d = jpegx_restore_ref((double)z[p], n, mode, param, T_QT);
@@ -94,10 +97,12 @@ int emul_inverse(const int16_t *in, int H, int W, int mode, double param, int32_
                 // the kernel's fp32 dequantisation: (float)z * fp32 multiplier (k_inverse_fused)
                 v[n] = (mode == JPEGX_QM_QTABLE) ? (float)z[p] * (float)T_QT[n]
                        : (mode == JPEGX_QM_DIVIDE ? (float)z[p] * (float)param : (float)z[p]);
-                if (n == 0) continue;
-                if (n < 8 || (n & 7) == 0) A1 += fabsf(v[n]); else A2 += fabsf(v[n]);
             }
-            const float E = jpegx_inv_err_bound(fabsf(v[0]), A1, A2, mode == JPEGX_QM_DIVIDE ? 2.f : 0.f);
+            // the kernel's weighted absolute sum, in its order (zigzag order of arrival, then the divide-mode extra)
+            for (int p = 0; p < 64; ++p) A = fmaf(fabsf(v[T_ZZ[p]]), jpegx_inv_weight(T_ZZ[p], 0), A);
+            if (mode == JPEGX_QM_DIVIDE)
+                for (int n = 0; n < 64; ++n) A = fmaf(fabsf(v[n]), jpegx_inv_weight(n, 2) - jpegx_inv_weight(n, 0), A);
+            const float E = jpegx_inv_err_from_weighted_sum(A);
             jpegx_idct8x8_f32(v);
             double u[8], m[64], y64[64], w[8];
             for (int j = 0; j < 8; ++j) {       // columns first
@@ -119,7 +124,7 @@ int emul_inverse(const int16_t *in, int H, int W, int mode, double param, int32_
                 double ratio = fabs((double)v[n] - y64[n]) / (double)(E > 0 ? E : 1e-30f);   /* observed error / bound */
                 if (ratio > maxratio) maxratio = ratio;
                 float r = rintf(v[n]);
-                int flag = (fabsf(v[n] - r) + E) >= 0.5f;
+                int flag = !((fabsf(v[n] - r) + E) < JPEGX_SAFE_HALF);
                 int res = flag ? (int)rint(y64[n]) : (int)r;
                 if (flag) { ++nflag; blkflag = 1; }
                 out[(size_t)(by * 8 + (n >> 3)) * W + bx * 8 + (n & 7)] = res;

@@ -182,7 +182,28 @@ def test_device_and_host_decoders_agree_on_damaged_streams(gpu):
     assert seen["equal"] >= 10 and seen["both refuse"] >= 100 and seen["device stricter"] <= 5, seen
 
 
-@pytest.mark.parametrize("bs", [1, 2, 4])
+def test_decoders_refuse_sign_only_codes_and_trailing_bytes(gpu):
+    """Two kinds of damaged stream the reference itself rejects: a code of size 1 -- a sign bit with
+    no amplitude bits, int('', 2) in rle_byte_stream.py:35-42 -- and bytes or whole blocks behind the last block of
+    the plane (the reference parses them and then fails in its reshape, run_length_encoding.py:77-79).  Device
+    decoder, C++ host parser and the Python step class all refuse them."""
+    from pipeline import Configuration, QuantizationMethod
+    from pipeline.rle_byte_stream import RleBytestream
+    z = np.zeros((4, 64), np.int16)
+    z[:, 3] = 5
+    good = oracle.rle_bytestream(z)
+    assert np.array_equal(gpu.entropy_decode_gpu(good, 4), z) and np.array_equal(gpu.entropy_decode(good, 4), z)
+    sign_only = bytes([0x01, 0x80, 0x00])                 # run 0, size 1, sign bit '1', then the end marker
+    for bad, n in ((sign_only, 1), (good + b"\x00", 4), (good + good[:len(good) // 4], 4), (good, 3), (good + b"\x07", 4)):
+        with pytest.raises(gpu.JpegxError):
+            gpu.entropy_decode_gpu(bad, n)
+        with pytest.raises(gpu.JpegxError):
+            gpu.entropy_decode(bad, n)
+    with pytest.raises(ValueError):
+        RleBytestream(Configuration(8, 8, 1, quantization=QuantizationMethod("none"))).invert(sign_only)
+
+
+@pytest.mark.parametrize("bs", [1, 2, 3, 4, 5])
 def test_decompress_plane_all_on_device(gpu, bs):
     """bytes -> samples without the coefficients ever visiting the host == host parse + fused inverse."""
     a = gpu.synth.generate_plane("noise", 256 * bs, 512 * bs, seed=8)

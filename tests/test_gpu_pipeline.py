@@ -4,6 +4,7 @@ the reference's outputs (golden vectors) as the expectation."""
 import numpy as np
 import pytest
 
+import oracle
 import pipeline
 import transforms
 from conftest import CASES
@@ -278,3 +279,128 @@ def test_block_size_3_runs_on_the_device_and_matches_the_reference(gpu, golden):
     assert gpu.compress_plane_native(band, 3, "qtable", 0.0) == compress_band(band, config_for(c, QuantizationMethod("qtable")))
     # a float64 plane straight into steps 4-6 (BasisChange input that is not exact in fp32)
     assert np.array_equal(pipeline._hot_forward(c["pre"], config_for(c, QuantizationMethod("qtable"))), c["zz_qtable"].astype(np.float64))
+
+
+def test_block_size_3_decompresses_in_one_native_call(gpu, golden):
+    """SubSampling.invert for a block_size the kernel does not know at compile time: the replication factor is a
+    run-time argument of the fused inverse (jpegx_inverse_fused_u8_inflated), so decompress_band with block_size 3
+    is one native job -- bytes up, device decoder, inverse + clamp + 3 x 3 replication, samples down -- and equals
+    the reference's band (case_pooled3x72.npz band_*)."""
+    c = golden("pooled3x72")
+    for suffix, mk in METHODS:
+        cfg = config_for(c, mk())
+        mode, param = mk().gpu_mode()
+        zz = c["zz_" + suffix]
+        blob = oracle.rle_bytestream(zz)
+        want = c["band_" + suffix]
+        hb, wb = zz.shape[:2]
+        assert np.array_equal(gpu.decompress_plane(blob, hb * 8, wb * 8, 3, mode, param), want.astype(np.uint8)), suffix
+        assert np.array_equal(gpu.inverse_fused_u8(zz, mode, param, inflate=3), want.astype(np.uint8))
+        assert np.array_equal(pipeline.decompress_band_u8(blob, cfg), want.astype(np.uint8))
+        assert np.array_equal(decompress_band(blob, cfg), want)
+    # other factors against plain replication of the un-inflated result
+    zz = c["zz_qtable"]
+    base = gpu.inverse_fused_u8(zz, "qtable", 0.0, inflate=1)
+    for rep in (5, 6, 7, 9, 16, 31):
+        assert np.array_equal(gpu.inverse_fused_u8(zz, "qtable", 0.0, inflate=rep), np.repeat(np.repeat(base, rep, axis=0), rep, axis=1)), rep
+
+
+@pytest.mark.parametrize("bs", [1, 2, 3])
+def test_whole_image_job_equals_three_band_jobs(gpu, bs):
+    """Jpeg.compress / Jpeg.decompress through ONE native job per picture (jpegx_host_compress_image /
+    _decompress_image: bands on two alternating streams, the bytes of band k copied into their own bytes object
+    while band k + 1 is computed, np.dstack done on the device): same container bytes as three compress_band calls
+    (pipeline/__init__.py:102-110), same picture as three decompress_band calls."""
+    from PIL import Image
+    import file_format
+    h, w = 96 * bs, 160 * bs
+    rgb = np.stack([gpu.synth.generate_plane("smooth", h, w, seed=s) for s in (1, 2, 3)], axis=-1).astype(np.uint8)
+    im = Image.fromarray(rgb, mode="RGB").convert("YCbCr")
+    for mk in (lambda: QuantizationMethod("qtable"), lambda: QuantizationMethod("divide", divisor=7)):
+        cfg = Configuration(width=w, height=h, block_size=bs, quantization=mk())
+        per_band = [compress_band(np.asarray(b), cfg) for b in im.split()]
+        blobs = gpu.compress_image_native([np.ascontiguousarray(np.asarray(b)) for b in im.split()], bs, *cfg.quantization.gpu_mode())
+        assert blobs == per_band
+        data = pipeline.Jpeg(cfg).compress(im)
+        assert data == file_format.generate_data(cfg, pipeline.CompressedData(*per_band))
+        back = pipeline.Jpeg.decompress(data)
+        want = np.dstack([pipeline.decompress_band_u8(b, cfg) for b in per_band])
+        assert np.array_equal(np.asarray(back), want)
+        planar = gpu.decompress_image_native(per_band, h // bs, w // bs, bs, *cfg.quantization.gpu_mode(), h, w, interleave=False)
+        assert np.array_equal(planar, np.moveaxis(want, 2, 0))
+    # a ragged picture (padding to the block size, cropping on the way back) and int64 bands
+    cfg = Configuration(width=150, height=90, block_size=1, quantization=QuantizationMethod("qtable"))
+    small = im.crop((0, 0, 150, 90))
+    data = pipeline.Jpeg(cfg).compress(small)
+    bands = [compress_band(np.asarray(b).astype(np.int64), cfg) for b in small.split()]
+    assert data == file_format.generate_data(cfg, pipeline.CompressedData(*bands))
+    assert np.array_equal(np.asarray(pipeline.Jpeg.decompress(data)), np.dstack([pipeline.decompress_band_u8(b, cfg) for b in bands]))
+
+
+def test_open_compress_job_refuses_a_second_pooled_call_on_its_thread(gpu):
+    """jpegx_host_compress_begin keeps the device's pool until _finish / _abort.  A second pooled entry on the SAME
+    thread -- another _begin, a host-pointer convenience, a decompress, a pool release -- used to lock the pool's
+    non-recursive mutex again and hang; now it returns JPEGX_E_INVALID, and _finish / _abort find the thread's own
+    job whatever the thread's current device is."""
+    import ctypes
+    L = gpu.lib()
+    band = gpu.synth.generate_plane("smooth", 64, 128, seed=3).astype(np.uint8)
+    n = ctypes.c_size_t(0)
+    gpu.check(L.jpegx_host_compress_begin(band.ctypes.data, 1, 64, 128, 128, 1, gpu.Q_QTABLE, 0.0, ctypes.byref(n)), "begin")
+    try:
+        assert L.jpegx_host_compress_begin(band.ctypes.data, 1, 64, 128, 128, 1, gpu.Q_QTABLE, 0.0, ctypes.byref(n)) == -1
+        assert b"open on this thread" in L.jpegx_last_error()
+        with pytest.raises(gpu.JpegxError):
+            gpu.forward_fused(band.astype(np.float32), "qtable")
+        with pytest.raises(gpu.JpegxError):
+            gpu.decompress_plane(b"\x00" * 128, 64, 128, 1, "qtable")
+        assert L.jpegx_host_pool_release() == -1
+    finally:
+        out = ctypes.create_string_buffer(max(1, n.value))
+        gpu.check(L.jpegx_host_compress_finish(out), "finish")
+    assert out.raw[:n.value] == gpu.compress_plane(band, 1, "qtable")
+    assert L.jpegx_host_compress_finish(out) == -1          # nothing open any more
+    assert L.jpegx_host_compress_abort() == 0
+
+
+def test_saturated_int16_is_not_mistaken_for_a_coefficient(gpu):
+    """_hot_forward's all-float64 kernel saturates to int16: a coefficient at or below -32768 must send the band
+    down the exact step-by-step road (np.abs of int16 -32768 wraps to -32768 and used to let it through, ADVICE
+    round 2).  A float64 plane whose samples are not fp32 numbers and whose first block has DC = -38421."""
+    pre = np.full((8, 16), 1.0 / 3.0)
+    pre[:, :8] = -600.0 - 1.0 / 3.0
+    cfg = Configuration(width=16, height=8, block_size=1, quantization=QuantizationMethod("none"))
+    want = oracle.zigzag_plane(oracle.quant_plane(oracle.dct_plane(pre), "none"))
+    assert want[0, 0, 0] == -38421.0
+    assert gpu.forward_fused_f64(pre, "none")[0, 0, 0] == -32768          # what the saturating kernel hands back
+    assert np.array_equal(pipeline._hot_forward(pre, cfg), want)
+
+
+def test_explicit_device_forms_of_the_entries(gpu):
+    """jpegx_<name>_on(device, ...): the same work with the device named in the call; the thread's
+    current device is left as it was, a device that does not exist is JPEGX_E_NODEVICE."""
+    import ctypes
+    L = gpu.lib()
+    a = gpu.synth.generate_plane("noise", 64, 128, seed=2).astype(np.uint8)
+    din, dzz = ctypes.c_void_p(), ctypes.c_void_p()
+    gpu.check(L.jpegx_malloc_on(0, ctypes.byref(din), a.nbytes), "malloc_on")
+    gpu.check(L.jpegx_malloc_on(0, ctypes.byref(dzz), a.size * 2), "malloc_on")
+    try:
+        gpu.check(L.jpegx_memcpy_h2d(din, a.ctypes.data, a.nbytes, None), "h2d")
+        gpu.check(L.jpegx_forward_fused_u8_on(0, din, 64, 128, 128, 1, gpu.Q_QTABLE, 0.0, 0, dzz, None), "forward_fused_u8_on")
+        zz = np.empty((8, 16, 64), np.int16)
+        gpu.check(L.jpegx_memcpy_d2h(zz.ctypes.data, dzz, zz.nbytes, None), "d2h")
+        gpu.check(L.jpegx_device_synchronize(), "sync")
+        assert np.array_equal(zz, oracle.forward_f32(a.astype(np.float32), "qtable"))
+        out = np.empty((64, 128), np.uint8)
+        blob = gpu.compress_plane(a, 1, "qtable")
+        buf = np.frombuffer(blob, np.uint8)
+        gpu.check(L.jpegx_host_decompress_plane_on(0, buf.ctypes.data, buf.size, 64, 128, 1, gpu.Q_QTABLE, 0.0, out.ctypes.data, 128), "decompress_on")
+        assert np.array_equal(out, gpu.decompress_plane(blob, 64, 128, 1, "qtable"))
+        assert L.jpegx_forward_fused_u8_on(63, din, 64, 128, 128, 1, gpu.Q_QTABLE, 0.0, 0, dzz, None) == -3
+        dev = ctypes.c_int(-1)
+        gpu.check(L.jpegx_get_device(ctypes.byref(dev)), "get_device")
+        assert dev.value == 0
+    finally:
+        L.jpegx_free_on(0, din)
+        L.jpegx_free_on(0, dzz)
