@@ -224,8 +224,8 @@ __global__ __launch_bounds__(256) void k_dec_starts(const unsigned *__restrict__
     start_pos[i] = p;
 }
 
-__global__ __launch_bounds__(64) void k_dec_blocks(const unsigned *__restrict__ words, size_t nbytes, const unsigned *__restrict__ start_pos,
-                                                   int nblk, int16_t *__restrict__ out, unsigned *__restrict__ head)
+__device__ __forceinline__ void dec_blocks_body(const unsigned *__restrict__ words, size_t nbytes, const unsigned *__restrict__ start_pos,
+                                                int nblk, int16_t *__restrict__ out, unsigned *__restrict__ head)
 {
     __shared__ __attribute__((aligned(16))) unsigned char lds[64 * 128];
     const int lane = threadIdx.x, g0 = blockIdx.x * 64, g = g0 + lane;
@@ -250,6 +250,348 @@ __global__ __launch_bounds__(64) void k_dec_blocks(const unsigned *__restrict__ 
     }
 }
 
+__global__ __launch_bounds__(64) void k_dec_blocks(const unsigned *__restrict__ words, size_t nbytes, const unsigned *__restrict__ start_pos,
+                                                   int nblk, int16_t *__restrict__ out, unsigned *__restrict__ head)
+{
+    dec_blocks_body(words, nbytes, start_pos, nblk, out, head);
+}
+
+// the same behind the segmented scheme: nothing to decode when that refused the stream or handed it back
+__global__ __launch_bounds__(64) void k_dec_blocks_guarded(const unsigned *__restrict__ words, size_t nbytes, const unsigned *__restrict__ start_pos,
+                                                           int nblk, int16_t *__restrict__ out, unsigned *__restrict__ head)
+{
+    if (head[1] != 0 || head[2] != 0) return;
+    dec_blocks_body(words, nbytes, start_pos, nblk, out, head);
+}
+
+// ================================================================================================
+// Round 3: block starts by SEGMENTS, five launches instead of fourteen and no host round trip.
+//
+// The pointer-jumping scheme above works on the whole stream at once: candidate compaction (3 launches), one
+// parse per candidate with a binary search in global memory for the candidate behind it, log4(blocks) jump
+// passes (8 launches for a 4096 x 4096 band, each a few microseconds of work) and a host read-back of the
+// candidate count in the middle.  What it does not use: a block is at most 185 bytes long, so everything about a
+// stretch of the stream can be resolved LOCALLY, in LDS, except which of a handful of candidates the chain of true
+// blocks enters the stretch at.
+//   k_seg_parse   one workgroup per segment of `seg` bytes: the segment (+ 256 bytes) into LDS, its candidates
+//                 compacted in order, one parse per candidate from LDS (the candidate behind it found by a binary
+//                 search in LDS), pointer doubling IN LDS.  For every candidate in the first 192 bytes -- the only
+//                 places the chain can enter at -- where the chain leaves the segment and how many blocks it passes.
+//   k_seg_entries which entry each segment is really entered at.  Chains merge within a block or two, so for almost
+//                 every segment all entries agree on the exit (a "constant" segment) and the entry of the next one
+//                 is known without looking further back; a thread walks back to the nearest constant segment
+//                 (bounded) and forward again.
+//   k_seg_scan    block index of every segment's first block (scan), and the proof: the chain from position 0,
+//                 segment by segment, is exactly the entries chosen (so the shortcut above can only cost time, never
+//                 correctness), ends at the stream's last byte and holds the plane's number of blocks.
+//   k_seg_starts  the segment's doubling tables again (from the persisted first level), block i's start position.
+//   k_dec_blocks  as before.
+// A stream this layout does not fit (more candidates in a segment than its tables hold: a quarter of its bytes
+// zero; more than 64 K segments) raises a flag and the host falls back to the scheme above.
+// ================================================================================================
+namespace seg {
+
+constexpr int THREADS = 128;              // two waves per segment: its ~60-200 candidates fill one or two, more would idle
+constexpr int REACH = 192;                 // a block is at most 185 bytes: the chain enters a segment within its first REACH bytes
+constexpr int EMAX = REACH + 1;
+constexpr unsigned INVALID = 0xFFFFu, END = 0xFFFEu, EXIT = 0x8000u;   // EXIT | position relative to the NEXT segment
+constexpr unsigned AFTER = 0xFFFDu;        // entry of a segment behind the stream's last block (a short tail segment)
+__device__ __forceinline__ bool is_exit(unsigned x) { return (x & EXIT) != 0 && x < AFTER; }
+constexpr int WALK_LIMIT = 64;
+
+struct Ws {
+    unsigned *head;        // [1] error bits, [2] fallback bits, [3] blocks found
+    unsigned *ncand, *nent, *konst, *entry, *count, *first;    // per segment
+    unsigned short *pos, *j0;                                   // [nseg][cmax]
+    unsigned short *ent_exit, *ent_cnt;                         // [nseg][EMAX]
+    unsigned *start_pos;                                        // [nblocks]
+};
+
+__host__ __device__ inline size_t up16(size_t v) { return (v + 15) & ~(size_t)15; }
+
+__host__ __device__ inline Ws carve(void *base, unsigned nseg, int cmax, long long nblocks, size_t *total = nullptr)
+{
+    unsigned char *p = static_cast<unsigned char *>(base);
+    size_t o = 16;
+    Ws w;
+    w.head = reinterpret_cast<unsigned *>(p);
+    unsigned **per[] = {&w.ncand, &w.nent, &w.konst, &w.entry, &w.count, &w.first};
+    for (unsigned **q : per) { *q = reinterpret_cast<unsigned *>(p + o); o += up16((size_t)nseg * 4); }
+    w.pos = reinterpret_cast<unsigned short *>(p + o); o += up16((size_t)nseg * cmax * 2);
+    w.j0 = reinterpret_cast<unsigned short *>(p + o); o += up16((size_t)nseg * cmax * 2);
+    w.ent_exit = reinterpret_cast<unsigned short *>(p + o); o += up16((size_t)nseg * EMAX * 2);
+    w.ent_cnt = reinterpret_cast<unsigned short *>(p + o); o += up16((size_t)nseg * EMAX * 2);
+    w.start_pos = reinterpret_cast<unsigned *>(p + o); o += up16((size_t)nblocks * 4);
+    if (total) *total = o;
+    return w;
+}
+
+// workgroup-wide exclusive scan of one value per thread; returns the exclusive prefix, *total = sum
+__device__ __forceinline__ unsigned block_scan(unsigned v, unsigned *s_part, unsigned *total)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    unsigned incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned u = __shfl_up(incl, d);
+        if (lane >= d) incl += u;
+    }
+    if (lane == 63) s_part[wv] = incl;
+    __syncthreads();
+    unsigned base = 0;
+    for (int k = 0; k < wv; ++k) base += s_part[k];
+    unsigned sum = 0;
+    for (int k = 0; k < THREADS / 64; ++k) sum += s_part[k];
+    *total = sum;
+    __syncthreads();
+    return base + incl - v;
+}
+
+// index of position `e` in the sorted list pos[lo, hi), or -1
+__device__ __forceinline__ int find_pos(const unsigned short *pos, int lo, int hi, unsigned e)
+{
+    const int end = hi;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (pos[mid] < e) lo = mid + 1; else hi = mid;
+    }
+    return (lo < end && pos[lo] == e) ? lo : -1;
+}
+
+// J[k][c] = the candidate 2^k blocks behind c, or the terminal code the chain meets before that
+__device__ __forceinline__ void double_up(unsigned short *J, int cmax, int levels, int n)
+{
+    for (int k = 1; k < levels; ++k) {
+        const unsigned short *prev = J + (size_t)(k - 1) * cmax;
+        unsigned short *cur = J + (size_t)k * cmax;
+        for (int c = threadIdx.x; c < n; c += THREADS) {
+            const unsigned a = prev[c];
+            cur[c] = (unsigned short)(a < EXIT ? prev[a] : a);
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(THREADS) void k_seg_parse(const unsigned char *__restrict__ bytes, size_t nbytes, int seg, int cmax, int levels,
+                                                       unsigned nseg, void *ws, long long nblocks)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+    __shared__ unsigned s_part[4];
+    __shared__ unsigned short s_exit[EMAX];
+    const Ws W = carve(ws, nseg, cmax, nblocks);
+    const int wwords = (seg + 264) / 4;                    // window: bytes [base - 4, base + seg + 260)
+    unsigned *sw = reinterpret_cast<unsigned *>(sm);
+    unsigned short *cpos = reinterpret_cast<unsigned short *>(sm + (size_t)wwords * 4);
+    unsigned short *J = cpos + cmax;
+    const unsigned s = blockIdx.x;
+    const int t = threadIdx.x;
+    const size_t base = (size_t)s * seg;
+    const size_t readable = (nbytes + 16) & ~(size_t)3;     // the buffer carries at least 16 zero bytes behind the stream
+    for (int i = t; i < wwords; i += THREADS) {
+        const long long off = (long long)base - 4 + 4LL * i;
+        unsigned v = 0;
+        if (off >= 0 && (size_t)off + 4 <= readable) v = *reinterpret_cast<const unsigned *>(bytes + off);
+        sw[i] = v;
+    }
+    __syncthreads();
+    // candidates in stream order: position 0, and every position behind a 0x00 byte
+    const unsigned char *sb = sm + 4;                        // sb[p] = byte at position base + p; sb[-1] is readable
+    const int per = seg / THREADS;                           // <= 64 (seg <= 8192)
+    unsigned long long mask = 0;
+    for (int i = 0; i < per; ++i) {
+        const int p = t * per + i;
+        const bool c = base + p < nbytes && (base + p == 0 || sb[p - 1] == 0);
+        mask |= (unsigned long long)c << i;
+    }
+    unsigned total = 0;
+    unsigned at = block_scan((unsigned)__popcll(mask), s_part, &total);
+    if (total > (unsigned)cmax || total == 0) {
+        // more zero bytes than the tables hold: the general scheme decides.  None at all: only the tail of the last
+        // block can look like that (k_seg_scan checks that nothing tries to enter here)
+        if (t == 0) {
+            if (total) atomicOr(&W.head[2], 1u);
+            W.ncand[s] = 0; W.nent[s] = 0; W.konst[s] = INVALID;
+        }
+        return;
+    }
+    while (mask) {
+        const int i = __ffsll((long long)mask) - 1;
+        mask &= mask - 1;
+        cpos[at++] = (unsigned short)(t * per + i);
+    }
+    __syncthreads();
+    // one parse per candidate, from LDS
+    const unsigned long long win_bits = (unsigned long long)(nbytes - base + 4) * 8u;
+    for (unsigned c = t; c < total; c += THREADS) {
+        const unsigned p = cpos[c];
+        const unsigned e = parse_block<false>(sw, win_bits, p + 4, nullptr, 0);
+        unsigned code = INVALID;
+        if (e != NIL) {
+            const unsigned er = e - 4;
+            if (base + er == nbytes) code = END;
+            else if (er >= (unsigned)seg) code = EXIT | (er - (unsigned)seg);
+            else {
+                const int i = find_pos(cpos, (int)c + 1, (int)total, er);
+                code = i < 0 ? INVALID : (unsigned)i;
+            }
+        }
+        J[c] = (unsigned short)code;
+    }
+    __syncthreads();
+    for (unsigned c = t; c < total; c += THREADS) {          // the first level and the positions stay for k_seg_starts
+        W.pos[(size_t)s * cmax + c] = cpos[c];
+        W.j0[(size_t)s * cmax + c] = J[c];
+    }
+    double_up(J, cmax, levels, (int)total);
+    // where the chain leaves, and after how many blocks, from every candidate it can enter at
+    unsigned nent = 0;
+    {
+        int lo = 0, hi = (int)total;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (cpos[mid] <= REACH) lo = mid + 1; else hi = mid; }
+        nent = (unsigned)lo;
+    }
+    for (unsigned j = t; j < nent; j += THREADS) {
+        unsigned cur = j, cnt = 0;
+        for (int k = levels - 1; k >= 0; --k) {
+            const unsigned n = J[(size_t)k * cmax + cur];
+            if (n < EXIT) { cur = n; cnt += 1u << k; }
+        }
+        const unsigned fin = J[cur];
+        s_exit[j] = (unsigned short)fin;
+        W.ent_exit[(size_t)s * EMAX + j] = (unsigned short)fin;
+        W.ent_cnt[(size_t)s * EMAX + j] = (unsigned short)(cnt + 1);
+    }
+    __syncthreads();
+    if (t == 0) {
+        unsigned k = INVALID;                                // the common exit of all entries that have one, else INVALID
+        bool same = true;
+        for (unsigned j = 0; j < nent; ++j) {
+            const unsigned x = s_exit[j];
+            if (x == INVALID) continue;
+            if (k == INVALID) k = x; else if (k != x) same = false;
+        }
+        W.ncand[s] = total;
+        W.nent[s] = nent;
+        W.konst[s] = same ? k : INVALID;
+    }
+}
+
+// entry (candidate index) of segment s given the position `rel` the chain arrives at, or -1
+__device__ __forceinline__ int entry_of(const Ws &W, unsigned s, int cmax, unsigned rel)
+{
+    return find_pos(W.pos + (size_t)s * cmax, 0, (int)W.nent[s], rel);
+}
+
+__global__ __launch_bounds__(THREADS) void k_seg_entries(unsigned nseg, int cmax, void *ws, long long nblocks)
+{
+    const Ws W = carve(ws, nseg, cmax, nblocks);
+    const unsigned s = blockIdx.x * THREADS + threadIdx.x;
+    if (s >= nseg) return;
+    unsigned entry = INVALID, count = 0;
+    if (s == 0) {
+        entry = W.nent[0] > 0 ? 0u : INVALID;               // position 0 is candidate 0 of segment 0
+    } else {
+        // nearest segment below whose exit does not depend on its entry (or segment 0, whose entry is known)
+        unsigned tq = s - 1;
+        int steps = 0;
+        while (tq > 0 && W.konst[tq] == INVALID && steps < WALK_LIMIT) { --tq; ++steps; }
+        unsigned x;                                           // what the chain leaves segment tq with
+        if (W.konst[tq] != INVALID) x = W.konst[tq];
+        else if (tq == 0 && W.nent[0] > 0) x = W.ent_exit[0];
+        else { atomicOr(&W.head[2], 4u); x = INVALID; }
+        for (unsigned u = tq + 1; u <= s && x != INVALID; ++u) {
+            if (x == END || x == AFTER) { x = AFTER; if (u == s) entry = AFTER; continue; }
+            const int j = is_exit(x) ? entry_of(W, u, cmax, x & 0x7FFFu) : -1;
+            if (j < 0) break;
+            if (u == s) entry = (unsigned)j; else x = W.ent_exit[(size_t)u * EMAX + j];
+        }
+    }
+    if (entry != INVALID && entry != AFTER) count = W.ent_cnt[(size_t)s * EMAX + entry];
+    W.entry[s] = entry;
+    W.count[s] = count;
+}
+
+// one workgroup: first block index of every segment (the proof that the entries chosen ARE the chain from 0 is spread
+// over the workgroups of k_seg_starts: every segment checks its own link to the next)
+__global__ __launch_bounds__(1024) void k_seg_scan(unsigned nseg, int cmax, void *ws, long long nblocks, size_t nbytes, int seg)
+{
+    __shared__ unsigned carry[16];
+    __shared__ unsigned base_s, bad_s;
+    const Ws W = carve(ws, nseg, cmax, nblocks);
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    if (t == 0) { base_s = 0; bad_s = 0; }
+    __syncthreads();
+    for (unsigned i0 = 0; i0 < nseg; i0 += 1024) {
+        const unsigned i = i0 + t;
+        unsigned v = 0;
+        bool bad = false;
+        if (i < nseg) {
+            v = W.count[i];
+            bad = W.entry[i] == INVALID;                       // the links between the entries are checked by k_seg_starts
+        }
+        if (bad) atomicOr(&bad_s, 1u);
+        unsigned incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned u = __shfl_up(incl, d);
+            if (lane >= d) incl += u;
+        }
+        if (lane == 63) carry[wv] = incl;
+        __syncthreads();
+        unsigned base = base_s;
+        for (int k = 0; k < wv; ++k) base += carry[k];
+        if (i < nseg) W.first[i] = base + incl - v;
+        __syncthreads();
+        if (t == 1023) base_s = base + incl;
+        __syncthreads();
+    }
+    if (t == 0) {
+        W.head[3] = base_s;
+        unsigned err = 0;
+        if (bad_s) err |= 2u;                                  // the chain breaks (a malformed block) or does not end at the last byte
+        if ((long long)base_s < nblocks) err |= 1u;            // fewer blocks than the plane has
+        if ((long long)base_s > nblocks) err |= 4u;            // more: bytes behind the plane's last block
+        if (err && !(W.head[2] & 7u)) atomicOr(&W.head[1], err);
+    }
+}
+
+__global__ __launch_bounds__(THREADS) void k_seg_starts(int seg, int cmax, int levels, unsigned nseg, void *ws, long long nblocks)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+    const Ws W = carve(ws, nseg, cmax, nblocks);
+    if (W.head[1] != 0 || W.head[2] != 0) return;           // refused or handed to the general scheme: nothing to write
+    unsigned short *cpos = reinterpret_cast<unsigned short *>(sm);
+    unsigned short *J = cpos + cmax;
+    const unsigned s = blockIdx.x;
+    const int t = threadIdx.x;
+    const unsigned n = W.ncand[s], entry = W.entry[s], count = W.count[s], first = W.first[s];
+    if (t == 0 && entry != INVALID && entry != AFTER) {
+        // the link to the next segment: what the chain leaves this segment with is where the next one is entered, or the
+        // stream's last byte (then nothing may follow).  All links + entry 0 of segment 0 = the chain from position 0.
+        const unsigned x = W.ent_exit[(size_t)s * EMAX + entry];
+        bool bad;
+        if (x == END) bad = s + 1 < nseg && W.entry[s + 1] != AFTER;
+        else if (s + 1 < nseg) bad = !is_exit(x) || entry_of(W, s + 1, cmax, x & 0x7FFFu) != (int)W.entry[s + 1];
+        else bad = true;
+        if (bad) atomicOr(&W.head[1], 2u);
+    }
+    if (count == 0 || entry == INVALID || entry == AFTER) return;
+    for (unsigned c = t; c < n; c += THREADS) {
+        cpos[c] = W.pos[(size_t)s * cmax + c];
+        J[c] = W.j0[(size_t)s * cmax + c];
+    }
+    __syncthreads();
+    double_up(J, cmax, levels, (int)n);
+    for (unsigned r = t; r < count; r += THREADS) {
+        unsigned cur = entry;
+        for (int k = 0; k < levels; ++k)
+            if ((r >> k) & 1u) cur = J[(size_t)k * cmax + cur];
+        if ((long long)(first + r) < nblocks) W.start_pos[first + r] = (unsigned)((size_t)s * seg) + cpos[cur];
+    }
+}
+
+}  // namespace seg
+
 }  // namespace
 
 namespace jpegx_decode {
@@ -259,6 +601,44 @@ int levels_for(long long nblocks)          // base-4 digits of the largest block
     int l = 1;
     while ((1ll << (2 * l)) < nblocks) ++l;
     return l;
+}
+
+// ---- segmented scheme (round 3) ----------------------------------------------------------------------------------
+SegPlan seg_plan(size_t nbytes, long long nblocks)
+{
+    SegPlan p;
+    // about four thousand segments for a large stream, segments of 4 KiB at least: typical candidates per segment
+    // (one per block + a third again) stay far below the tables' capacity of a quarter of the bytes
+    int sg = 4096;
+    while (sg < 8192 && nbytes / (size_t)sg > 16384) sg *= 2;
+    p.seg = sg;
+    // table capacity: twice the candidates an average segment holds (one per block and about a third again from zero
+    // bytes inside amplitudes), as a power of two between 128 and a quarter of the segment's bytes -- the tables are
+    // what limits how many segments a CU works on at a time
+    const double per_seg = 1.4 * (double)sg * (double)(nblocks > 0 ? nblocks : 1) / (double)(nbytes ? nbytes : 1);
+    int cm = 128;
+    while (cm < sg / 4 && (double)cm < 2.0 * per_seg) cm *= 2;
+    p.cmax = cm;
+    p.levels = 1;
+    while ((1 << (p.levels - 1)) < p.cmax) ++p.levels;
+    p.nseg = (unsigned)((nbytes + sg - 1) / sg);
+    p.ok = nbytes > 0 && p.nseg <= 262144u && nblocks > 0;
+    seg::carve(nullptr, p.nseg ? p.nseg : 1, p.cmax, nblocks > 0 ? nblocks : 1, &p.ws_bytes);
+    return p;
+}
+
+void enqueue_segmented(const uint8_t *d_bytes, size_t nbytes, long long nblocks, const SegPlan &p, void *d_ws, int16_t *d_zz, hipStream_t st)
+{
+    (void)hipMemsetAsync(d_ws, 0, 16, st);
+    const size_t lds_parse = (size_t)((p.seg + 264) / 4) * 4 + (size_t)p.cmax * 2 * (1 + p.levels);
+    const size_t lds_starts = (size_t)p.cmax * 2 * (1 + p.levels);
+    hipLaunchKernelGGL(seg::k_seg_parse, dim3(p.nseg), dim3(seg::THREADS), lds_parse, st, d_bytes, nbytes, p.seg, p.cmax, p.levels, p.nseg, d_ws, nblocks);
+    hipLaunchKernelGGL(seg::k_seg_entries, dim3((p.nseg + seg::THREADS - 1) / seg::THREADS), dim3(seg::THREADS), 0, st, p.nseg, p.cmax, d_ws, nblocks);
+    hipLaunchKernelGGL(seg::k_seg_scan, dim3(1), dim3(1024), 0, st, p.nseg, p.cmax, d_ws, nblocks, nbytes, p.seg);
+    hipLaunchKernelGGL(seg::k_seg_starts, dim3(p.nseg), dim3(seg::THREADS), lds_starts, st, p.seg, p.cmax, p.levels, p.nseg, d_ws, nblocks);
+    const seg::Ws W = seg::carve(d_ws, p.nseg, p.cmax, nblocks);
+    hipLaunchKernelGGL(k_dec_blocks_guarded, dim3((unsigned)((nblocks + 63) / 64)), dim3(64), 0, st, reinterpret_cast<const unsigned *>(d_bytes), nbytes,
+                       W.start_pos, (int)nblocks, d_zz, W.head);
 }
 
 size_t phase1_bytes(size_t nbytes) { return 16 + ((nbytes + CHUNK - 1) / CHUNK + 1) * 4; }

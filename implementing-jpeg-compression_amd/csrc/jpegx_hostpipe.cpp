@@ -434,11 +434,28 @@ int jpegx_host_compress_image(const void *const *h_planes, int nbands, int elem_
 }  // extern "C"
 
 namespace {
-// bytes already on the device (slot.d_in, padded) -> int16 stream in slot.d_zz; the caller holds the pool
-int decode_on_device(BandSlot &slot, size_t nbytes, long long nblocks, hipStream_t st)
+// bytes already on the device (slot.d_in, padded) -> int16 stream in slot.d_zz; the caller holds the pool.
+// general = false: the segmented scheme (jpegx_entropy_decode.hip, round 3) -- five launches whose workspace depends
+// on the stream's length only, no host round trip; decode_status afterwards may answer DECODE_RETRY_GENERAL for a
+// stream its tables do not fit.  general = true: the pointer-jumping scheme over the whole stream, which reads the
+// candidate count back in the middle.
+constexpr int DECODE_RETRY_GENERAL = 1;
+
+int decode_on_device(BandSlot &slot, size_t nbytes, long long nblocks, hipStream_t st, bool general)
 {
     int rc;
-    if ((rc = slot.d_ws.ensure(jpegx_decode::phase1_bytes(nbytes))) || (rc = slot.d_zz.ensure((size_t)nblocks * 128))) return rc;
+    if ((rc = slot.d_zz.ensure((size_t)nblocks * 128))) return rc;
+    const jpegx_decode::SegPlan plan = jpegx_decode::seg_plan(nbytes, nblocks);
+    const char *force = getenv("JPEGX_DECODE_GENERAL");    // tests / A-B runs: the general scheme from the start
+    if (force && *force && *force != '0') general = true;
+    if (!general && plan.ok) {
+        if ((rc = slot.d_ws.ensure(plan.ws_bytes))) return rc;
+        jpegx_decode::enqueue_segmented(static_cast<const uint8_t *>(slot.d_in.p), nbytes, nblocks, plan, slot.d_ws.p,
+                                        static_cast<int16_t *>(slot.d_zz.p), st);
+        HP_TRY(hipGetLastError());
+        return JPEGX_OK;
+    }
+    if ((rc = slot.d_ws.ensure(jpegx_decode::phase1_bytes(nbytes)))) return rc;
     jpegx_decode::enqueue_phase1(static_cast<const uint8_t *>(slot.d_in.p), nbytes, slot.d_ws.p, st);
     unsigned head[4] = {0, 0, 0, 0};
     HP_TRY(hipMemcpyAsync(head, slot.d_ws.p, 16, hipMemcpyDeviceToHost, st));
@@ -452,10 +469,14 @@ int decode_on_device(BandSlot &slot, size_t nbytes, long long nblocks, hipStream
     return JPEGX_OK;
 }
 
-int decode_status(BandSlot &slot)     // after the stream has been synchronised
+// after the stream has been synchronised: JPEGX_OK, an error, or DECODE_RETRY_GENERAL
+int decode_status(BandSlot &slot, bool general)
 {
     unsigned head[4] = {0, 0, 0, 0};
     HP_TRY(hipMemcpy(head, slot.d_ws.p, 16, hipMemcpyDeviceToHost));
+    const char *force = getenv("JPEGX_DECODE_GENERAL");
+    if (force && *force && *force != '0') general = true;
+    if (!general && head[2] != 0) return DECODE_RETRY_GENERAL;
     if (head[1] != 0) return fail(JPEGX_E_INVALID, "entropy stream is not a sequence of well-formed blocks (device decoder)");
     return JPEGX_OK;
 }
@@ -473,14 +494,14 @@ int check_decompress_shape(const uint8_t *h_bytes, size_t nbytes, int H, int W, 
 // upload + device entropy decoding + fused inverse (clamp, SubSampling.invert) of one band into slot.d_out
 // ([H*bs][dev_pitch] bytes), all on `st`
 int enqueue_back(BandSlot &slot, const uint8_t *h_bytes, size_t nbytes, int H, int W, int bs, int mode, double param,
-                 ptrdiff_t dev_pitch, hipStream_t st)
+                 ptrdiff_t dev_pitch, hipStream_t st, bool general)
 {
     const long long nblocks = (long long)(H / 8) * (W / 8);
     int rc;
     if ((rc = slot.d_in.ensure(nbytes + 16)) || (rc = slot.d_out.ensure((size_t)H * bs * dev_pitch))) return rc;
     HP_TRY(hipMemsetAsync(static_cast<uint8_t *>(slot.d_in.p) + (nbytes & ~(size_t)3), 0, 16 + (nbytes & 3), st));   // zero tail (whole dwords)
     HP_TRY(hipMemcpyAsync(slot.d_in.p, h_bytes, nbytes, hipMemcpyHostToDevice, st));
-    if ((rc = decode_on_device(slot, nbytes, nblocks, st))) return rc;
+    if ((rc = decode_on_device(slot, nbytes, nblocks, st, general))) return rc;
     return jpegx_inverse_fused_u8_inflated(static_cast<const int16_t *>(slot.d_zz.p), H, W, mode, param, 0, bs,
                                            static_cast<uint8_t *>(slot.d_out.p), dev_pitch, st);
 }
@@ -502,10 +523,13 @@ static int decompress_plane_locked(DevicePool *pool, const uint8_t *h_bytes, siz
     if ((rc = ensure_streams(pool, false))) return rc;
     hipStream_t st = pool->stream;
     BandSlot &slot = pool->slot[0];
-    if ((rc = enqueue_back(slot, h_bytes, nbytes, H, W, bs, mode, param, out_pitch, st))) return rc;
-    HP_TRY(hipMemcpyAsync(h_out, slot.d_out.p, (size_t)H * bs * out_pitch, hipMemcpyDeviceToHost, st));
-    HP_TRY(hipStreamSynchronize(st));
-    return decode_status(slot);
+    for (int general = 0; general < 2; ++general) {
+        if ((rc = enqueue_back(slot, h_bytes, nbytes, H, W, bs, mode, param, out_pitch, st, general != 0))) return rc;
+        HP_TRY(hipMemcpyAsync(h_out, slot.d_out.p, (size_t)H * bs * out_pitch, hipMemcpyDeviceToHost, st));
+        HP_TRY(hipStreamSynchronize(st));
+        if ((rc = decode_status(slot, general != 0)) != DECODE_RETRY_GENERAL) return rc;
+    }
+    return fail(JPEGX_E_INVALID, "device decoder: no scheme took the stream");
 }
 
 int jpegx_host_decompress_plane(const uint8_t *h_bytes, size_t nbytes, int H, int W, int bs, int mode, double param,
@@ -579,40 +603,53 @@ int jpegx_host_decompress_image(const uint8_t *const *h_bytes, const size_t *nby
     std::thread toucher(prefault, h_out, out_span);
     struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{toucher};
     auto drain = [&]() { (void)hipStreamSynchronize(pool->aux[0]); (void)hipStreamSynchronize(pool->aux[1]); };
-    for (int k = 0; k < nbands; ++k) {
-        hipStream_t st = pool->aux[k & 1];
-        if ((rc = enqueue_back(pool->slot[k], h_bytes[k], nbytes[k], H, W, bs, mode, param, dev_pitch, st))) { drain(); return rc; }
-        if (!interleave) {
-            if (hipMemcpy2DAsync(h_out + (size_t)k * rows * out_pitch, (size_t)out_pitch, pool->slot[k].d_out.p, (size_t)dev_pitch,
-                                 (size_t)cols, (size_t)rows, hipMemcpyDeviceToHost, st) != hipSuccess) {
+    bool general[MAX_BANDS] = {};                           // bands the segmented decoder handed back
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        for (int k = 0; k < nbands; ++k) {
+            hipStream_t st = pool->aux[k & 1];
+            if (attempt && !general[k]) {                    // this band is done: only the packing below waits for it again
+                if (interleave && hipEventRecord(pool->ev[k], st) != hipSuccess) { drain(); return fail(JPEGX_E_HIP, "hipEventRecord failed"); }
+                continue;
+            }
+            if ((rc = enqueue_back(pool->slot[k], h_bytes[k], nbytes[k], H, W, bs, mode, param, dev_pitch, st, general[k]))) { drain(); return rc; }
+            if (!interleave) {
+                if (hipMemcpy2DAsync(h_out + (size_t)k * rows * out_pitch, (size_t)out_pitch, pool->slot[k].d_out.p, (size_t)dev_pitch,
+                                     (size_t)cols, (size_t)rows, hipMemcpyDeviceToHost, st) != hipSuccess) {
+                    drain();
+                    return fail(JPEGX_E_HIP, "device to host copy failed");
+                }
+            } else if (hipEventRecord(pool->ev[k], st) != hipSuccess) {
+                drain();
+                return fail(JPEGX_E_HIP, "hipEventRecord failed");
+            }
+        }
+        if (interleave) {
+            // the packing kernel runs on stream 0 behind every band
+            hipStream_t st = pool->aux[0];
+            const void *planes[MAX_BANDS] = {};
+            for (int k = 0; k < nbands; ++k) {
+                planes[k] = pool->slot[k].d_out.p;
+                if (k != 0 && hipStreamWaitEvent(st, pool->ev[k], 0) != hipSuccess) { drain(); return fail(JPEGX_E_HIP, "hipStreamWaitEvent failed"); }
+            }
+            uint8_t *packed = static_cast<uint8_t *>(pool->d_packed.p);
+            if ((rc = jpegx_interleave_u8(planes, nbands, rows, cols, dev_pitch, packed, (ptrdiff_t)packed_pitch, st))) { drain(); return rc; }
+            if (hipMemcpy2DAsync(h_out, (size_t)out_pitch, packed, packed_pitch, packed_pitch, (size_t)rows, hipMemcpyDeviceToHost, st) != hipSuccess) {
                 drain();
                 return fail(JPEGX_E_HIP, "device to host copy failed");
             }
-        } else if (hipEventRecord(pool->ev[k], st) != hipSuccess) {
-            drain();
-            return fail(JPEGX_E_HIP, "hipEventRecord failed");
         }
-    }
-    if (interleave) {
-        // the packing kernel runs on stream 0 behind every band
-        hipStream_t st = pool->aux[0];
-        const void *planes[MAX_BANDS] = {};
+        HP_TRY(hipStreamSynchronize(pool->aux[0]));
+        HP_TRY(hipStreamSynchronize(pool->aux[1]));
+        bool again = false;
         for (int k = 0; k < nbands; ++k) {
-            planes[k] = pool->slot[k].d_out.p;
-            if (k != 0 && hipStreamWaitEvent(st, pool->ev[k], 0) != hipSuccess) { drain(); return fail(JPEGX_E_HIP, "hipStreamWaitEvent failed"); }
+            if (attempt && !general[k]) continue;
+            rc = decode_status(pool->slot[k], general[k]);
+            if (rc == DECODE_RETRY_GENERAL) { general[k] = true; again = true; }
+            else if (rc) return rc;
         }
-        uint8_t *packed = static_cast<uint8_t *>(pool->d_packed.p);
-        if ((rc = jpegx_interleave_u8(planes, nbands, rows, cols, dev_pitch, packed, (ptrdiff_t)packed_pitch, st))) { drain(); return rc; }
-        if (hipMemcpy2DAsync(h_out, (size_t)out_pitch, packed, packed_pitch, packed_pitch, (size_t)rows, hipMemcpyDeviceToHost, st) != hipSuccess) {
-            drain();
-            return fail(JPEGX_E_HIP, "device to host copy failed");
-        }
+        if (!again) return JPEGX_OK;
     }
-    HP_TRY(hipStreamSynchronize(pool->aux[0]));
-    HP_TRY(hipStreamSynchronize(pool->aux[1]));
-    for (int k = 0; k < nbands; ++k)
-        if ((rc = decode_status(pool->slot[k]))) return rc;
-    return JPEGX_OK;
+    return fail(JPEGX_E_INVALID, "device decoder: no scheme took the stream");
 }
 
 // bytes -> int16 [nblocks][64] on the device, host arrays in and out (what jpegx_host_entropy_decode does on the CPU)
@@ -631,10 +668,13 @@ int jpegx_host_entropy_decode_gpu(const uint8_t *h_bytes, size_t nbytes, long lo
     if ((rc = slot.d_in.ensure(nbytes + 16))) return rc;
     HP_TRY(hipMemsetAsync(static_cast<uint8_t *>(slot.d_in.p) + (nbytes & ~(size_t)3), 0, 16 + (nbytes & 3), st));
     HP_TRY(hipMemcpyAsync(slot.d_in.p, h_bytes, nbytes, hipMemcpyHostToDevice, st));
-    if ((rc = decode_on_device(slot, nbytes, nblocks, st))) return rc;
-    HP_TRY(hipMemcpyAsync(h_zz, slot.d_zz.p, (size_t)nblocks * 128, hipMemcpyDeviceToHost, st));
-    HP_TRY(hipStreamSynchronize(st));
-    return decode_status(slot);
+    for (int general = 0; general < 2; ++general) {
+        if ((rc = decode_on_device(slot, nbytes, nblocks, st, general != 0))) return rc;
+        HP_TRY(hipMemcpyAsync(h_zz, slot.d_zz.p, (size_t)nblocks * 128, hipMemcpyDeviceToHost, st));
+        HP_TRY(hipStreamSynchronize(st));
+        if ((rc = decode_status(slot, general != 0)) != DECODE_RETRY_GENERAL) return rc;
+    }
+    return fail(JPEGX_E_INVALID, "device decoder: no scheme took the stream");
 }
 
 // used by host_roundtrip (jpegx_internal.h): the synchronous host-pointer conveniences borrow the pool's

@@ -127,16 +127,22 @@ JPEGX_HD float jpegx_fwd_err_bound(float S) { return S * 0x1p-20f; }
 // Coefficient (k, l) goes through the row pass (output index l; exact adds only there, its outputs are
 // arbitrary reals) and the column pass (output index k), each erring by at most (roundings) u S because
 // |C| <= 1 and every intermediate is bounded by the abs sums; the fp32 reciprocal and the product of the
-// quantiser add 2 u S.  So |t32 - t64| <= F(k, l) u S |1/q| with F = n_row(l) + n_col(k) + 2 between 5 and 14
-// (average 10.75 for pixel input) instead of the uniform 16; 2^-10 relative margin covers the O(u^2) terms
-// and the fp32 evaluation of S and of the bound itself.
+// quantiser add 2 u S (1 u S since round 3, see below).  So |t32 - t64| <= F(k, l) u S |1/q| with
+// F = n_row(l) + n_col(k) + 2 between 5 and 14 (average 10.75 for pixel input) instead of the uniform 16; 2^-10
+// relative margin covers the O(u^2) terms and the fp32 evaluation of S and of the bound itself.
 constexpr int jpegx_dct8_roundings(int k, bool exact_adds)
 {
     return k == 0 ? (exact_adds ? 0 : 3) : ((k & 1) ? (exact_adds ? 5 : 6) : (k == 4 ? (exact_adds ? 2 : 5) : (exact_adds ? 3 : 5)));
 }
+// Round 3: (a) the quantiser term is 1, not 2 -- jpegx_quant_fast rounds the EXACT product v * rq, so only the fp32
+// rounding of the reciprocal is left (the rounding to the integer is the decision itself, and the rounding of the
+// distance d is absorbed by JPEGX_SAFE_HALF); (b) with pixel input the row pass's output l = 0 is the exact sum of
+// eight samples, so for the coefficients (k, 0) of the first column the COLUMN pass works on exact integers too and
+// its butterfly adds are exact as well -- those are the coefficients with the largest multipliers 1/q, i.e. the
+// ones that raise most flags.
 constexpr int jpegx_fwd_roundings(int n, bool pixel_input)   // n = k * 8 + l
 {
-    return jpegx_dct8_roundings(n & 7, pixel_input) + jpegx_dct8_roundings(n >> 3, false) + 2;
+    return jpegx_dct8_roundings(n & 7, pixel_input) + jpegx_dct8_roundings(n >> 3, pixel_input && (n & 7) == 0) + 1;
 }
 JPEGX_HD float jpegx_fwd_err_unit(float S) { return S * 0x1.004p-24f; }   // u S (1 + 2^-10)
 

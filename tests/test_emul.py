@@ -71,7 +71,10 @@ def test_forward_two_tier_large(emul, kind):
     for mode, param in (("qtable", 0.0), ("divide", 7.0), ("none", 0.0)):
         got, st = run_forward(emul, a, mode, param, 1)
         assert np.array_equal(got, oracle.forward_f32(a, mode, param))
-        assert st[2] < 0.6           # typical error sits well inside the bound
+        # typical error sits well inside the bound; the worst case on these planes is the DC coefficient under
+        # `divide 7`: it is computed exactly, the bound charges one rounding (that of the fp32 reciprocal) and
+        # fl32(1/7) happens to be off by 0.75 u
+        assert st[2] < 0.8
     _, st = run_forward(emul, a, "qtable", 0.0, 1)
     assert st[1] / (a.size / 64) < 0.08   # exact-tier share of blocks stays small for the JPEG table
 

@@ -182,6 +182,38 @@ def test_device_and_host_decoders_agree_on_damaged_streams(gpu):
     assert seen["equal"] >= 10 and seen["both refuse"] >= 100 and seen["device stricter"] <= 5, seen
 
 
+def test_segmented_and_general_decoders_agree(gpu, monkeypatch):
+    """The two device schemes for finding block starts -- by segments in LDS (five launches, no host round trip) and by
+    pointer jumping over the whole stream (the fallback) -- give the same coefficients as the host parser, on streams
+    that exercise the segment logic: blocks straddling segment boundaries, segments whose entries disagree, a last
+    segment holding only the tail of the last block, all-zero planes (every byte a block: more candidates than a
+    segment's tables hold, so the segmented scheme hands the stream back), sparse and dense content."""
+    rng = np.random.default_rng(12)
+    streams = []
+    for nblocks, density, amp in ((5000, 0.9, 300), (20000, 0.2, 40), (3000, 0.02, 4), (700, 1.0, 16383), (4099, 0.5, 2000)):
+        z = (rng.integers(-amp, amp + 1, (nblocks, 64)) * (rng.random((nblocks, 64)) < density)).astype(np.int16)
+        z[::7, ::3] = rng.choice(np.array([256, -512, 4096, 8192, -16384 + 256, 1, -1], dtype=np.int16), z[::7, ::3].shape)
+        streams.append(z)
+    streams.append(np.zeros((9000, 64), np.int16))                      # 9000 bytes of 0x00
+    streams.append(np.zeros((1, 64), np.int16))
+    for z in streams:
+        blob = oracle.rle_bytestream(z.reshape(len(z), 1, 64))
+        host = gpu.entropy_decode(blob, len(z))
+        assert np.array_equal(host, z)
+        monkeypatch.delenv("JPEGX_DECODE_GENERAL", raising=False)
+        assert np.array_equal(gpu.entropy_decode_gpu(blob, len(z)), z), len(z)
+        monkeypatch.setenv("JPEGX_DECODE_GENERAL", "1")
+        assert np.array_equal(gpu.entropy_decode_gpu(blob, len(z)), z), len(z)
+        monkeypatch.delenv("JPEGX_DECODE_GENERAL", raising=False)
+        # cut the stream so that the last segment holds a few bytes only (sizes around multiples of 4096)
+        sizes = np.cumsum(oracle.rle_bytestream(z.reshape(len(z), 1, 64), want_block_bytes=True)[1]) if len(z) > 1 else None
+        if sizes is not None and sizes[-1] > 9000:
+            for target in (4096, 8192):
+                i = int(np.searchsorted(sizes, target + 2))
+                if 0 < i < len(z):
+                    assert np.array_equal(gpu.entropy_decode_gpu(blob[:int(sizes[i])], i + 1), z[:i + 1]), (len(z), target)
+
+
 def test_decoders_refuse_sign_only_codes_and_trailing_bytes(gpu):
     """Two kinds of damaged stream the reference itself rejects: a code of size 1 -- a sign bit with
     no amplitude bits, int('', 2) in rle_byte_stream.py:35-42 -- and bytes or whole blocks behind the last block of
