@@ -206,7 +206,8 @@ __device__ __forceinline__ double coop_inv_exact(double z_own, double *sA, doubl
 // pieces shared by the forward kernels
 // ------------------------------------------------------------------------------------------------
 
-// Quantise the 64 coefficients of v (natural order) in zigzag order and pack them as int16 pairs
+// Quantise the 64 coefficients of v (natural order, as jpegx_dct8x8_aan_f32 leaves them: scaled by g_k g_l, the
+// multipliers in prm.rq32 carry 1 / (g_k g_l)) in zigzag order and pack them as int16 pairs
 // (pipeline/quantization.py:8-18 + pipeline/zigzag_order.py:85-99; the zigzag is a compile-time
 // renaming).  E = u S (jpegx_fwd_err_unit); a coefficient's bound is E F(k, l) / q with F = jpegx_fwd_roundings.
 // Returns the worst rounding margin max(|t - rint(t)| + E F / q): the block is safe iff it stays below JPEGX_SAFE_HALF.
@@ -228,9 +229,9 @@ __device__ __forceinline__ float quantise_zigzag_pack(const float (&v)[64], cons
                                                       unsigned (&pk)[32])
 {
     float worst = 0.f;
-    float Ef[15];                       // E = u S (jpegx_fwd_err_unit) times the coefficient's rounding count F(k, l)
+    float Ef[JPEGX_AAN_LEVELS];         // E = u S (jpegx_fwd_err_unit) times the bound's factor F(k, l), by level (jpegx_math.h)
 #pragma unroll
-    for (int j = 0; j < 15; ++j) Ef[j] = E * (float)j;
+    for (int j = 0; j < JPEGX_AAN_LEVELS; ++j) Ef[j] = E * jpegx_aan_level(j, PIXEL);
     float magic = JPEGX_RMAGIC;
     asm volatile("" : "+v"(magic));     // one live register, see jpegx_quant_fast_m
 #pragma unroll
@@ -242,7 +243,7 @@ __device__ __forceinline__ float quantise_zigzag_pack(const float (&v)[64], cons
             const float rq = prm.rq32[n];
             float d;
             m[h] = jpegx_quant_fast_m(v[n], rq, magic, d);
-            if (!(DC_EXACT && n == 0)) worst = fmaxf(worst, fmaf(Ef[jpegx_fwd_roundings(n, PIXEL)], fabsf(rq), fabsf(d)));
+            if (!(DC_EXACT && n == 0)) worst = fmaxf(worst, fmaf(Ef[jpegx_aan_level_index(n, PIXEL)], fabsf(rq), fabsf(d)));
             if (!PIXEL) m[h] = clamp_magic_i16(m[h]);
         }
         pk[p >> 1] = pack_magic_pair(m[0], m[1]);
@@ -258,9 +259,9 @@ __device__ __forceinline__ unsigned quantise_zigzag_pack_cols(const float (&v)[6
                                                               unsigned (&pk)[32])
 {
     float worst[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    float Ef[15];
+    float Ef[JPEGX_AAN_LEVELS];
 #pragma unroll
-    for (int j = 0; j < 15; ++j) Ef[j] = E * (float)j;
+    for (int j = 0; j < JPEGX_AAN_LEVELS; ++j) Ef[j] = E * jpegx_aan_level(j, PIXEL);
     float magic = JPEGX_RMAGIC;
     asm volatile("" : "+v"(magic));
 #pragma unroll
@@ -272,7 +273,7 @@ __device__ __forceinline__ unsigned quantise_zigzag_pack_cols(const float (&v)[6
             const float rq = prm.rq32[n];
             float d;
             m[h] = jpegx_quant_fast_m(v[n], rq, magic, d);
-            if (!(DC_EXACT && n == 0)) worst[n & 7] = fmaxf(worst[n & 7], fmaf(Ef[jpegx_fwd_roundings(n, PIXEL)], fabsf(rq), fabsf(d)));
+            if (!(DC_EXACT && n == 0)) worst[n & 7] = fmaxf(worst[n & 7], fmaf(Ef[jpegx_aan_level_index(n, PIXEL)], fabsf(rq), fabsf(d)));
             if (!PIXEL) m[h] = clamp_magic_i16(m[h]);
         }
         pk[p >> 1] = pack_magic_pair(m[0], m[1]);

@@ -187,7 +187,7 @@ __device__ __forceinline__ void forward_fused_body(unsigned char *lds, int wg, c
 #pragma unroll
         for (int n = 0; n < 64; ++n) S += fabsf(v[n]);
     }
-    jpegx_dct8x8_f32(v);
+    jpegx_dct8x8_aan_f32(v);
     if (PIXEL) S = v[0];  // non-negative samples: sum|x| == DC, exact
     // generic pooled input: the fp32 tile sums are themselves rounded (<= BS^2 u each)
     const float E = jpegx_fwd_err_unit(S) * ((PIXEL || BS == 1) ? 1.0f : 1.0f + (BS * BS) / 16.0f);
@@ -372,7 +372,7 @@ __device__ __forceinline__ void forward_strip_body(unsigned char *lds, int wg, c
 #pragma unroll
         for (int n = 0; n < 64; ++n) S += fabsf(v[n]);
     }
-    jpegx_dct8x8_f32(v);
+    jpegx_dct8x8_aan_f32(v);
     if (PIXEL) S = v[0];
     const float E = jpegx_fwd_err_unit(S);
 
@@ -514,7 +514,7 @@ __global__ __launch_bounds__(64) void k_forward_fused_strip_cols(const float *__
 #pragma unroll
         for (int n = 0; n < 64; ++n) S += fabsf(v[n]);
     }
-    jpegx_dct8x8_f32(v);
+    jpegx_dct8x8_aan_f32(v);
     if (PIXEL) S = v[0];
     const float E = jpegx_fwd_err_unit(S);
     unsigned pk[32];
@@ -998,15 +998,14 @@ __global__ __launch_bounds__(64) JPEGX_U8_OCC void k_forward_fused_u8(const unsi
     // the inverse zigzag order -- one LDS-DMA instruction) and, for BS = 4, 128 bytes through which the owner of a
     // flagged block hands its tile sums to the wave: the tier issues NO vector memory load (under the streaming
     // load such a load waits for microseconds; k_inverse_fused has the measurement)
-    // (BS = 1 keeps the constant-memory tables: there the 1 KiB and the extra live values cost a wave of occupancy
-    // and 3 % -- 24.3 vs 25.1 Gblocks/s -- while BS = 2 gains 6 % and BS = 4, which also re-read its samples from
-    // memory, 9 %: profiles/r02_ab_u8_exact_tier.txt)
-    constexpr bool TABBED = BS != 1;
+    // (round 2 kept the constant-memory tables for BS = 1 because the extra KiB cost a wave of occupancy; since round 3
+    // that variant's LDS is the 8 KiB of its output tile whatever lives inside, so its tier is load-free as well)
+    constexpr bool TABBED = true;
     // BS = 1: the input rows fill only the first 4 KiB of the 8 KiB that become the output tile, so the exact tier's
     // scratch and patch area live in the second half (dead before the tile is written): 8 KiB of LDS in all = 20
     // waves per CU, which the 94 registers of this variant allow (5 per SIMD)
     constexpr int SCR = (BS == 1) ? IN_BYTES : FRONT;
-    static_assert(BS != 1 || IN_BYTES + SCRATCH_DOUBLES * 8 + 128 <= TILE_BYTES, "scratch fits behind the rows");
+    static_assert(BS != 1 || IN_BYTES + SCRATCH_DOUBLES * 8 + 128 + 1024 <= TILE_BYTES, "scratch and table fit behind the rows");
     constexpr int U8_PATCH = SCR + SCRATCH_DOUBLES * 8, U8_TAB = U8_PATCH + 128, U8_XBLK = U8_TAB + (TABBED ? 1024 : 0);
     __shared__ __attribute__((aligned(16))) unsigned char lds[BS == 1 ? TILE_BYTES : U8_XBLK + (BS == 4 ? 128 : 0)];
     double *sA = reinterpret_cast<double *>(lds + SCR);
@@ -1128,7 +1127,7 @@ __global__ __launch_bounds__(64) JPEGX_U8_OCC void k_forward_fused_u8(const unsi
         }
     }
 
-    jpegx_dct8x8_f32(v);
+    jpegx_dct8x8_aan_f32(v);
     const float E = jpegx_fwd_err_unit(v[0]);             // pixel input: sum|x| == DC, exact
     unsigned pk[32];
     const float worst = quantise_zigzag_pack<true, DC_EXACT>(v, prm, E, pk);
@@ -1362,8 +1361,10 @@ int launch_forward(const float *d_in, int H, int W, ptrdiff_t pitch, const Quant
         QuantParams q2 = qp;
         dim3 g2 = grid;
         q2.tune |= xcd_order_setup(flags, nblk, &g2);
+        const bool cols = (flags & JPEGX_F_TUNE_COLUMN_UNITS) || (expected_exact_share(qp) > 0.03 && !(flags & JPEGX_F_TUNE_NO_COLUMN_UNITS));
+        scale_for_aan(&q2);                         // the fast tier works on the scaled (AAN) coefficients
         // column-wise exact tier once more than ~3 % of the blocks are expected to be flagged
-        if ((flags & JPEGX_F_TUNE_COLUMN_UNITS) || (expected_exact_share(qp) > 0.03 && !(flags & JPEGX_F_TUNE_NO_COLUMN_UNITS))) {
+        if (cols) {
             if (dc_exact)
                 hipLaunchKernelGGL((k_forward_fused_strip_cols<3, NT>), g2, block, 0, st, d_in, (size_t)pitch, wb, nblk, q2, d_out, g_counters);
             else if (pixel)
@@ -1379,12 +1380,16 @@ int launch_forward(const float *d_in, int H, int W, ptrdiff_t pitch, const Quant
             hipLaunchKernelGGL((k_forward_fused_strip<1, NT>), g2, block, 0, st, d_in, (size_t)pitch, wb, nblk, q2, d_out, g_counters);
         else
             hipLaunchKernelGGL((k_forward_fused_strip<0, NT>), g2, block, 0, st, d_in, (size_t)pitch, wb, nblk, q2, d_out, g_counters);
-    } else if (dc_exact)
-        hipLaunchKernelGGL((k_forward_fused<3, BS, NT, STAGED>), grid, block, 0, st, d_in, (size_t)pitch, wb, nblk, qp, d_out, g_counters);
-    else if (pixel)
-        hipLaunchKernelGGL((k_forward_fused<1, BS, NT, STAGED>), grid, block, 0, st, d_in, (size_t)pitch, wb, nblk, qp, d_out, g_counters);
-    else
-        hipLaunchKernelGGL((k_forward_fused<0, BS, NT, STAGED>), grid, block, 0, st, d_in, (size_t)pitch, wb, nblk, qp, d_out, g_counters);
+    } else {
+        QuantParams qa = qp;
+        scale_for_aan(&qa);
+        if (dc_exact)
+            hipLaunchKernelGGL((k_forward_fused<3, BS, NT, STAGED>), grid, block, 0, st, d_in, (size_t)pitch, wb, nblk, qa, d_out, g_counters);
+        else if (pixel)
+            hipLaunchKernelGGL((k_forward_fused<1, BS, NT, STAGED>), grid, block, 0, st, d_in, (size_t)pitch, wb, nblk, qa, d_out, g_counters);
+        else
+            hipLaunchKernelGGL((k_forward_fused<0, BS, NT, STAGED>), grid, block, 0, st, d_in, (size_t)pitch, wb, nblk, qa, d_out, g_counters);
+    }
     HIP_TRY(hipGetLastError());
     return JPEGX_OK;
 }
@@ -1466,9 +1471,11 @@ int jpegx_forward_fused_planes(const jpegx_plane_desc *planes, int nplanes, int 
     const bool nt = !(flags & JPEGX_F_TUNE_NO_NT);
     const dim3 grid((unsigned)wg), block(64);
     hipStream_t st = (hipStream_t)stream;
+    QuantParams qa = qp;
+    scale_for_aan(&qa);
 #define JPEGX_LP(VARV) \
-    do { if (nt) hipLaunchKernelGGL((k_forward_fused_planes<VARV, true>), grid, block, 0, st, tab, qp, g_counters); \
-         else hipLaunchKernelGGL((k_forward_fused_planes<VARV, false>), grid, block, 0, st, tab, qp, g_counters); } while (0)
+    do { if (nt) hipLaunchKernelGGL((k_forward_fused_planes<VARV, true>), grid, block, 0, st, tab, qa, g_counters); \
+         else hipLaunchKernelGGL((k_forward_fused_planes<VARV, false>), grid, block, 0, st, tab, qa, g_counters); } while (0)
     if (dc_exact) JPEGX_LP(3); else if (pixel) JPEGX_LP(1); else JPEGX_LP(0);
 #undef JPEGX_LP
     HIP_TRY(hipGetLastError());
@@ -1527,9 +1534,11 @@ int jpegx_forward_fused_u8(const uint8_t *d_in, int H, int W, ptrdiff_t pitch, i
     hipStream_t st = (hipStream_t)stream;
     const bool dc_exact = is_pow2_float(qp.rq32[0]) && (qp.mode != JPEGX_Q_DIVIDE || (double)qp.rq32[0] * qp.param == 1.0);
     const bool nt = !(flags & JPEGX_F_TUNE_NO_NT);
+    QuantParams qa = qp;
+    scale_for_aan(&qa);
 #define JPEGX_LU8(DC, BSV) \
-    do { if (nt) hipLaunchKernelGGL((k_forward_fused_u8<DC, BSV, true>), grid, block, 0, st, d_in, (size_t)pitch, wb, nblk, qp, d_out, g_counters); \
-         else hipLaunchKernelGGL((k_forward_fused_u8<DC, BSV, false>), grid, block, 0, st, d_in, (size_t)pitch, wb, nblk, qp, d_out, g_counters); } while (0)
+    do { if (nt) hipLaunchKernelGGL((k_forward_fused_u8<DC, BSV, true>), grid, block, 0, st, d_in, (size_t)pitch, wb, nblk, qa, d_out, g_counters); \
+         else hipLaunchKernelGGL((k_forward_fused_u8<DC, BSV, false>), grid, block, 0, st, d_in, (size_t)pitch, wb, nblk, qa, d_out, g_counters); } while (0)
     if (bs == 1) { if (dc_exact) JPEGX_LU8(true, 1); else JPEGX_LU8(false, 1); }
     else if (bs == 2) { if (dc_exact) JPEGX_LU8(true, 2); else JPEGX_LU8(false, 2); }
     else { if (dc_exact) JPEGX_LU8(true, 4); else JPEGX_LU8(false, 4); }

@@ -103,6 +103,27 @@ int fill_forward_params(int mode, double param, QuantParams *qp)
     }
 }
 
+// The fused forward kernels run the scaled (AAN) transform: coefficient (k, l) comes out multiplied by g_k g_l
+// (jpegx_math.h), so their multipliers are the quantiser's reciprocals divided by that -- formed in double and rounded
+// to fp32 once, like the plain reciprocals.  Everything that reasons about the quantiser itself (kernel choice, DC
+// exactness, the int16 range) looks at the unscaled table from fill_forward_params.
+void scale_for_aan(QuantParams *qp)
+{
+    static const double g[8] = {JPEGX_AAN_G};
+    double rq[64];
+    switch (qp->mode) {
+    case JPEGX_Q_QTABLE:
+        for (int n = 0; n < 64; ++n) rq[n] = 1.0 / (double)kQT.v[n];
+        break;
+    case JPEGX_Q_DIVIDE:
+        for (int n = 0; n < 64; ++n) rq[n] = 1.0 / qp->param;
+        break;
+    default:
+        for (int n = 0; n < 64; ++n) rq[n] = (double)qp->rq32[n];      // 1 or 0: exact
+    }
+    for (int n = 0; n < 64; ++n) qp->rq32[n] = (float)(rq[n] / (g[n >> 3] * g[n & 7]));
+}
+
 // inverse table: fp32 multipliers of Quantizer.restore
 int fill_inverse_params(int mode, double param, QuantParams *qp)
 {

@@ -108,6 +108,75 @@ JPEGX_HD void jpegx_idct8x8_f32(float (&v)[64])
                         v[i * 8 + 4], v[i * 8 + 5], v[i * 8 + 6], v[i * 8 + 7]);
 }
 
+// ---------------------------------------------------------------------------------------------
+// fp32 fast tier, round 3: the forward transform of the fused kernels as an Arai-Agui-Nakajima flow graph with
+// the multiply-adds fused -- 30 operations per 8-point transform instead of 35 (the kernels that launch it are bound
+// by their instruction count).  Output k is JPEGX_AAN_G[k] times the un-normalised DCT-II coefficient of
+// transforms.py:4-11; the host folds 1 / (g_k g_l) into the quantiser's reciprocals (jpegx_internal.h:
+// scale_for_aan), so the quantised integers are those of the plain form wherever the bound lets the fast tier decide.
+// The bound's factors F(k, l) -- |v rq' - t64| <= F u S |rq'| -- are not counted by hand any more: tests/derive_bounds.py
+// runs this very flow graph symbolically (standard model of rounding, first order) and prints them; the kernels
+// keep E * level for 15 levels, every F rounded UP to its level (levels are multiples of 1/64).
+// tests/test_host_properties.py re-derives the factors and checks that every level here covers them; tests/test_emul.py
+// checks the bound against observed errors on adversarial blocks.
+// ---------------------------------------------------------------------------------------------
+#define JPEGX_AAN_G \
+    1, 1.9615705608064609, 1.8477590650225733, 1.6629392246050902, 1.4142135623730947, 1.1111404660392048, 0.76536686473017901, 0.3901806440322565
+#define JPEGX_A2M6 0.54119610014619698440f   /* cos(2 pi/16) - cos(6 pi/16) */
+#define JPEGX_A2P6 1.30656296487637652786f   /* cos(2 pi/16) + cos(6 pi/16) */
+
+JPEGX_HD void jpegx_dct8_aan_f32(float &x0, float &x1, float &x2, float &x3, float &x4, float &x5, float &x6, float &x7)
+{
+    const float t0 = x0 + x7, t7 = x0 - x7, t1 = x1 + x6, t6 = x1 - x6;
+    const float t2 = x2 + x5, t5 = x2 - x5, t3 = x3 + x4, t4 = x3 - x4;
+    const float t10 = t0 + t3, t13 = t0 - t3, t11 = t1 + t2, t12 = t1 - t2;
+    x0 = t10 + t11;
+    x4 = t10 - t11;
+    const float s = t12 + t13;
+    x2 = fmaf(s, JPEGX_A4, t13);
+    x6 = fmaf(s, -JPEGX_A4, t13);
+    const float a10 = t4 + t5, a11 = t5 + t6, a12 = t6 + t7;
+    const float z5 = (a10 - a12) * JPEGX_A6;
+    const float z2 = fmaf(a10, JPEGX_A2M6, z5);
+    const float z4 = fmaf(a12, JPEGX_A2P6, z5);
+    const float z11 = fmaf(a11, JPEGX_A4, t7), z13 = fmaf(a11, -JPEGX_A4, t7);
+    x5 = z13 + z2;
+    x3 = z13 - z2;
+    x1 = z11 + z4;
+    x7 = z11 - z4;
+}
+
+// 2-D forward on a block held as v[row*8+col]: rows first, then columns; v[k*8+l] = g_k g_l * coefficient (k, l)
+JPEGX_HD void jpegx_dct8x8_aan_f32(float (&v)[64])
+{
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        jpegx_dct8_aan_f32(v[i * 8 + 0], v[i * 8 + 1], v[i * 8 + 2], v[i * 8 + 3],
+                           v[i * 8 + 4], v[i * 8 + 5], v[i * 8 + 6], v[i * 8 + 7]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        jpegx_dct8_aan_f32(v[0 * 8 + j], v[1 * 8 + j], v[2 * 8 + j], v[3 * 8 + j],
+                           v[4 * 8 + j], v[5 * 8 + j], v[6 * 8 + j], v[7 * 8 + j]);
+}
+
+constexpr int JPEGX_AAN_LEVELS = 15;
+struct JpegxAanLevels { float level[JPEGX_AAN_LEVELS]; unsigned char index[64]; };
+constexpr JpegxAanLevels jpegx_aan_levels_pixel = {
+    {1.000000f, 2.125000f, 4.312500f, 5.015625f, 5.671875f, 6.921875f, 8.015625f, 10.109375f, 11.953125f, 13.625000f, 18.203125f, 22.453125f, 26.375000f, 30.718750f, 35.640625f},
+    {0, 9, 7, 8, 0, 6, 2, 4, 6, 14, 12, 13, 6, 11, 8, 8, 2, 12, 10, 11, 2, 10, 7, 7, 5, 13, 11, 12, 5, 10, 7, 7, 0, 9, 7, 8, 0, 6, 2, 4, 3, 11, 10, 10, 3, 8, 5, 5, 1, 9, 8, 8, 1, 6, 3, 2, 3, 11, 10, 10, 3, 8, 6, 2}};
+constexpr JpegxAanLevels jpegx_aan_levels_generic = {
+    {4.515625f, 7.000000f, 7.968750f, 10.843750f, 12.453125f, 13.375000f, 15.718750f, 18.390625f, 18.812500f, 21.921875f, 25.703125f, 28.671875f, 34.093750f, 37.734375f, 44.812500f},
+    {1, 7, 5, 6, 1, 3, 1, 3, 7, 14, 12, 13, 7, 10, 6, 9, 5, 12, 10, 11, 5, 9, 4, 8, 6, 13, 11, 12, 6, 9, 5, 8, 1, 7, 5, 6, 1, 3, 1, 3, 3, 10, 9, 9, 3, 6, 3, 4, 1, 6, 4, 5, 1, 3, 1, 2, 3, 9, 8, 8, 3, 4, 2, 0}};
+// level index of coefficient n = k * 8 + l
+constexpr int jpegx_aan_level_index(int n, bool pixel_input)
+{
+    return pixel_input ? jpegx_aan_levels_pixel.index[n] : jpegx_aan_levels_generic.index[n];
+}
+constexpr float jpegx_aan_level(int j, bool pixel_input)
+{
+    return pixel_input ? jpegx_aan_levels_pixel.level[j] : jpegx_aan_levels_generic.level[j];
+}
+
 // Rigorous bound on |fp32 fast-tier coefficient - float64 reference coefficient| for a block
 // whose samples have absolute sum S (any fp32 inputs).  Derivation in DESIGN.md ("error
 // bound"): every intermediate of either pass is bounded by the running absolute sums, each

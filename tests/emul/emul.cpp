@@ -37,7 +37,7 @@ int emul_forward(const float *in, int H, int W, int mode, double param, const fl
                     v[i * 8 + j] = x; a[i * 8 + j] = (double)x;
                     S += fabsf(x);
                 }
-            jpegx_dct8x8_f32(v);
+            jpegx_dct8x8_aan_f32(v);                 // scaled: v[k*8+l] = g_k g_l * coefficient (k, l)
             if (pixel_input) S = v[0];
             const float E = jpegx_fwd_err_unit(S);
             // exact tier for everything (for statistics only)
@@ -50,8 +50,9 @@ int emul_forward(const float *in, int H, int W, int mode, double param, const fl
             int blkflag = 0;
             for (int p = 0; p < 64; ++p) {
                 int n = T_ZZ[p];
-                if (out_dct32) out_dct32[(size_t)(by * 8 + (n >> 3)) * W + bx * 8 + (n & 7)] = v[n];
-                const int F = jpegx_fwd_roundings(n, pixel_input != 0);
+                static const double G[8] = {JPEGX_AAN_G};
+                if (out_dct32) out_dct32[(size_t)(by * 8 + (n >> 3)) * W + bx * 8 + (n & 7)] = (float)((double)v[n] / (G[n >> 3] * G[n & 7]));
+                const float F = jpegx_aan_level(jpegx_aan_level_index(n, pixel_input != 0), pixel_input != 0);
                 /* observed |v rq - t64| against the kernel's bound E F |1/q| (v rq: the exact product the fast tier
                    rounds, jpegx_quant_fast; the bound still charges a product rounding that is no longer made) */
                 double t = (double)v[n] * (double)rq32[n];
@@ -62,7 +63,7 @@ int emul_forward(const float *in, int H, int W, int mode, double param, const fl
                 float d;
                 const float mg = jpegx_quant_fast(v[n], rq32[n], d);
                 const float r = mg - JPEGX_RMAGIC;
-                float g = fmaf(E * (float)F, fabsf(rq32[n]), fabsf(d));
+                float g = fmaf(E * F, fabsf(rq32[n]), fabsf(d));
                 int flag = !(g < JPEGX_SAFE_HALF);
                 if (dc_exact && n == 0) flag = 0;
                 int res;

@@ -28,17 +28,25 @@ def _p(a, t):
     return a.ctypes.data_as(ctypes.POINTER(t))
 
 
+AAN_G = np.array([1, 1.9615705608064609, 1.8477590650225733, 1.6629392246050902, 1.4142135623730947, 1.1111404660392048,
+                  0.76536686473017901, 0.3901806440322565])       # JPEGX_AAN_G (csrc/jpegx_math.h, tests/derive_bounds.py)
+
+
 def rq_table(mode, param):
-    qt = oracle.tables()["qtable"].ravel()
+    """The fp32 multipliers the fused kernels get: the quantiser's reciprocal with the scale of the AAN transform's
+    output folded in, formed in double and rounded once (jpegx_internal.h scale_for_aan)."""
+    qt = oracle.tables()["qtable"].ravel().astype(np.float64)
     if mode == "qtable":
-        return (1.0 / qt).astype(np.float32)
-    if mode == "none":
-        return np.ones(64, np.float32)
-    if mode == "divide":
-        return np.full(64, np.float32(1.0 / param))
-    r = np.zeros((8, 8), np.float32)
-    r[:int(param), :int(param)] = 1
-    return r.ravel()
+        r = 1.0 / qt
+    elif mode == "none":
+        r = np.ones(64)
+    elif mode == "divide":
+        r = np.full(64, 1.0 / param)
+    else:
+        r = np.zeros((8, 8))
+        r[:int(param), :int(param)] = 1
+        r = r.ravel()
+    return (r / np.outer(AAN_G, AAN_G).ravel()).astype(np.float32)
 
 
 def run_forward(lib, plane, mode, param, pixel):
