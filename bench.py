@@ -255,6 +255,50 @@ def config4(jpegx, kind, iters, verify, planes=16):
     return res
 
 
+def config_u8(jpegx, kind, iters, verify, planes=16):
+    """The kernels the reference-API path launches (compress_band / decompress_band on 8-bit bands, block_size 1):
+    k_forward_fused_u8 (64 B of uint8 samples read + 128 B of int16 written per block) and k_inverse_fused<u8>
+    (128 B read + 64 B of clamped uint8 written): 192 algorithmic bytes per block each, 16 planes 4096^2 resident."""
+    n = 4096
+    H = n * planes
+    f32 = jpegx.DeviceBuffer(n * n * 4)
+    u8 = jpegx.DeviceBuffer(H * n)
+    zz = jpegx.DeviceBuffer(H * n * 2)
+    rec = jpegx.DeviceBuffer(H * n)
+    first = None
+    for p in range(planes):                                  # setup only: planes generated on the device, narrowed on the host
+        jpegx.generate_plane_device(f32.ptr, n, n, kind, seed=0, plane=p)
+        plane = f32.download((n, n), np.float32).astype(np.uint8)
+        if p == 0:
+            first = plane
+        u8.upload(plane, offset=p * n * n)
+    blocks = (H // 8) * (n // 8)
+
+    def fwd():
+        jpegx.forward_fused_u8_device(u8.ptr, H, n, zz.ptr, "qtable", 0.0, 0)
+
+    def inv():
+        jpegx.check(jpegx.lib().jpegx_inverse_fused_u8_inflated(zz.ptr, H, n, jpegx.Q_QTABLE, 0.0, 0, 1, rec.ptr, n, None), "inverse_u8")
+    fwd()
+    ms_f = _timed_launches(jpegx, fwd, iters)
+    ms_i = _timed_launches(jpegx, inv, iters)
+    res = {}
+    for name, ms in (("forward_u8_bs1", ms_f), ("inverse_u8", ms_i)):
+        res[name] = {"ms": round(ms, 4), "blocks": blocks, "algorithmic_bytes": blocks * 192, "Mblocks_per_s": round(blocks / ms / 1e3, 1),
+                     "GBps": round(blocks * 192 / ms / 1e6, 1), "frac": round(blocks * 192 / ms / 1e6 / HBM_PEAK_GBPS, 4)}
+    if verify:
+        import oracle
+        rows = 256
+        want = oracle.forward_f32(first[:rows].astype(np.float32), "qtable")
+        got = zz.download((rows // 8, n // 8, 64), np.int16)
+        back = rec.download((rows, n), np.uint8)
+        res["verified_vs_oracle"] = bool(np.array_equal(got, want) and
+                                         np.array_equal(back, np.clip(oracle.inverse_i16(want, "qtable"), 0, 255).astype(np.uint8)))
+    for b in (f32, u8, zz, rec):
+        b.free()
+    return res
+
+
 # --------------------------------------------------------------------------------------------------
 GATHER_FAILED_STATUS = 3       # exit status of every rank when the exchange (gather legs) failed or timed out
 
@@ -430,15 +474,17 @@ def run(args, rank, local_rank, world, ctl, emit):
     # HBM traffic per launch from the committed rocprofv3 PMC passes of this same command, accepted only
     # while the kernel sources are the ones that were profiled (profiles/summarize.py records their hash)
     traffic = traffic_src = None
-    try:
-        with open(os.path.join(REPO, "profiles", "r02_forward_summary.json")) as f:
-            prof = json.load(f)
-        if prof.get("forward_source_sha16") == forward_source_hash() and args.mode == "qtable":
-            traffic = prof["hbm_traffic"]["bytes_per_block"] * blocks_per_step
-            traffic_src = "profiles/r02_forward_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel, " \
-                          "%.2f B per block, scaled to this launch's blocks)" % prof["hbm_traffic"]["bytes_per_block"]
-    except Exception:
-        traffic = None
+    for tag in ("r03", "r02"):
+        try:
+            with open(os.path.join(REPO, "profiles", "%s_forward_summary.json" % tag)) as f:
+                prof = json.load(f)
+            if prof.get("forward_source_sha16") == forward_source_hash() and args.mode == "qtable":
+                traffic = prof["hbm_traffic"]["bytes_per_block"] * blocks_per_step
+                traffic_src = "profiles/%s_forward_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel, " \
+                              "%.2f B per block, scaled to this launch's blocks)" % (tag, prof["hbm_traffic"]["bytes_per_block"])
+                break
+        except Exception:
+            traffic = None
     result = {
         "metric": "M 8x8 blocks/sec (DCT+quant+zigzag)",
         "value": round(value, 2), "unit": "Mblocks/s", "n_gpus": world, "steps": args.steps,
@@ -505,7 +551,7 @@ def run(args, rank, local_rank, world, ctl, emit):
             b_in.free()
             iters = max(10, min(50, args.steps))
             cfg = {}
-            for name, fn in (("c3_8192_ycbcr420_forward", config3), ("c4_4096_round_trip", config4)):
+            for name, fn in (("c3_8192_ycbcr420_forward", config3), ("c4_4096_round_trip", config4), ("u8_band_kernels", config_u8)):
                 cfg[name] = {}
                 for kind in ("noise", "smooth"):
                     try:

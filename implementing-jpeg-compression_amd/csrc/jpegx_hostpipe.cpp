@@ -189,6 +189,31 @@ bool narrow_rows(const T *src, ptrdiff_t src_pitch, int H, int W, uint8_t *dst, 
     return ok;
 }
 
+// Touch every page of a (usually fresh) result buffer with a few host threads: the kernel hands out zeroed pages one
+// fault at a time, and left to the copy that lands in them this costs more than the copy (the 7-10 ms outliers of
+// decompress_band in round 2's profiles were exactly that: the first touch of a 128 MiB NumPy result).
+void prefault(uint8_t *p, size_t n)
+{
+    if (n < (4u << 20)) return;
+    const unsigned hw = std::thread::hardware_concurrency();
+    const int nthreads = hw >= 8 ? 8 : (hw ? (int)hw : 1);
+    auto work = [&](size_t a, size_t b) {
+        for (size_t o = a; o < b; o += 4096) reinterpret_cast<volatile uint8_t *>(p)[o] = 0;
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < nthreads; ++t) th.emplace_back(work, n * t / nthreads, n * (t + 1) / nthreads);
+    work(0, n / nthreads);
+    for (auto &t : th) t.join();
+}
+
+// the same on a helper thread for the duration of a scope: the pages are touched while the device works
+struct BackgroundTouch {
+    std::thread t;
+    BackgroundTouch(void *p, size_t n) : t(prefault, static_cast<uint8_t *>(p), n) {}
+    ~BackgroundTouch() { if (t.joinable()) t.join(); }
+    void wait() { if (t.joinable()) t.join(); }
+};
+
 int check_compress_shape(const void *h_plane, int elem_size, int H, int W, ptrdiff_t pitch, int bs)
 {
     if (!h_plane) return fail(JPEGX_E_INVALID, "null pointer");
@@ -342,20 +367,6 @@ int jpegx_host_compress_abort(void)
 // destination's pages are touched by a few host threads (fresh memory: the kernel hands out zeroed pages one fault
 // at a time, which costs more than the copy itself) while the emit kernels run, then every band's bytes are
 // copied from the device straight to their place.
-static void prefault(uint8_t *p, size_t n)
-{
-    if (n < (4u << 20)) return;
-    const unsigned hw = std::thread::hardware_concurrency();
-    const int nthreads = hw >= 8 ? 8 : (hw ? (int)hw : 1);
-    auto work = [&](size_t a, size_t b) {
-        for (size_t o = a; o < b; o += 4096) reinterpret_cast<volatile uint8_t *>(p)[o] = 0;
-    };
-    std::vector<std::thread> th;
-    for (int t = 1; t < nthreads; ++t) th.emplace_back(work, n * t / nthreads, n * (t + 1) / nthreads);
-    work(0, n / nthreads);
-    for (auto &t : th) t.join();
-}
-
 int jpegx_host_compress_image(const void *const *h_planes, int nbands, int elem_size, int H, int W, ptrdiff_t pitch, int bs,
                               int mode, double param, const void *prefix, size_t prefix_len, int length_prefixes,
                               jpegx_alloc_fn alloc, void *user, size_t *nbytes)
@@ -513,7 +524,7 @@ extern "C" {
 // transform 'DCT', dct_size 8): bytes up, entropy decoding ON THE DEVICE (jpegx_entropy_decode.hip), fused
 // inverse with clamp and SubSampling.invert (any block_size), uint8 samples down.  h_out: [H*bs][out_pitch] bytes.
 static int decompress_plane_locked(DevicePool *pool, const uint8_t *h_bytes, size_t nbytes, int H, int W, int bs, int mode,
-                                   double param, uint8_t *h_out, ptrdiff_t out_pitch)
+                                   double param, uint8_t *h_out, ptrdiff_t out_pitch, bool fresh_out)
 {
     int rc = check_decompress_shape(h_bytes, nbytes, H, W, bs);
     if (rc) return rc;
@@ -523,8 +534,10 @@ static int decompress_plane_locked(DevicePool *pool, const uint8_t *h_bytes, siz
     if ((rc = ensure_streams(pool, false))) return rc;
     hipStream_t st = pool->stream;
     BandSlot &slot = pool->slot[0];
+    BackgroundTouch touch(h_out, fresh_out ? (size_t)H * bs * out_pitch : 0);       // a fresh result array: fault its pages in meanwhile
     for (int general = 0; general < 2; ++general) {
         if ((rc = enqueue_back(slot, h_bytes, nbytes, H, W, bs, mode, param, out_pitch, st, general != 0))) return rc;
+        touch.wait();
         HP_TRY(hipMemcpyAsync(h_out, slot.d_out.p, (size_t)H * bs * out_pitch, hipMemcpyDeviceToHost, st));
         HP_TRY(hipStreamSynchronize(st));
         if ((rc = decode_status(slot, general != 0)) != DECODE_RETRY_GENERAL) return rc;
@@ -537,7 +550,7 @@ int jpegx_host_decompress_plane(const uint8_t *h_bytes, size_t nbytes, int H, in
 {
     PoolLock lock;
     if (lock.rc) return lock.rc;
-    return decompress_plane_locked(lock.pool, h_bytes, nbytes, H, W, bs, mode, param, h_out, out_pitch);
+    return decompress_plane_locked(lock.pool, h_bytes, nbytes, H, W, bs, mode, param, h_out, out_pitch, true);
 }
 
 // The same, handing back what the reference's decompress_band returns: a [rows][cols] int64 array (the band
@@ -556,7 +569,9 @@ int jpegx_host_decompress_plane_i64(const uint8_t *h_bytes, size_t nbytes, int H
     int rc;
     if ((rc = pool->h_out.ensure(stage_bytes))) return rc;
     uint8_t *stage = static_cast<uint8_t *>(pool->h_out.p);
-    if ((rc = decompress_plane_locked(pool, h_bytes, nbytes, H, W, bs, mode, param, stage, pitch))) return rc;
+    BackgroundTouch touch(h_out, (size_t)rows * cols * sizeof(int64_t));   // 128 MiB for a 4096 x 4096 band, usually never touched before
+    if ((rc = decompress_plane_locked(pool, h_bytes, nbytes, H, W, bs, mode, param, stage, pitch, false))) return rc;
+    touch.wait();
     const unsigned hw = std::thread::hardware_concurrency();
     const int nthreads = ((size_t)rows * cols < (1u << 20)) ? 1 : (hw >= 8 ? 8 : (hw ? (int)hw : 1));
     auto work = [&](int y0, int y1) {
@@ -600,8 +615,7 @@ int jpegx_host_decompress_image(const uint8_t *const *h_bytes, const size_t *nby
     if (interleave && (rc = pool->d_packed.ensure((size_t)rows * packed_pitch))) return rc;      // before anything is enqueued
     // the result array is usually fresh memory: touch its pages on a helper thread while the bands are uploaded and decoded
     const size_t out_span = interleave ? (size_t)rows * out_pitch : (size_t)nbands * rows * out_pitch;
-    std::thread toucher(prefault, h_out, out_span);
-    struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{toucher};
+    BackgroundTouch touch(h_out, out_span);
     auto drain = [&]() { (void)hipStreamSynchronize(pool->aux[0]); (void)hipStreamSynchronize(pool->aux[1]); };
     bool general[MAX_BANDS] = {};                           // bands the segmented decoder handed back
     for (int attempt = 0; attempt < 2; ++attempt) {

@@ -22,9 +22,25 @@ def best(fn, n=3):
     return min(ts), out
 
 
+def fresh_result_cost(shape, dtype, n=5):
+    """What the operating system charges for a fresh result array of this size, with no codec involved: allocate it and
+    touch every page once (ms, median).  decompress_band returns such an array; outliers of its wall time that match
+    this figure are the allocator's, not the pipeline's."""
+    ts = []
+    for _ in range(n):
+        t0 = time.perf_counter()
+        a = np.empty(shape, dtype)
+        a.reshape(-1)[::4096 // a.itemsize] = 0
+        ts.append((time.perf_counter() - t0) * 1e3)
+        del a
+    return sorted(ts)[len(ts) // 2]
+
+
 def main():
     jpegx.require_device()
     size = 4096
+    print("fresh 4096x4096 result arrays, allocate + touch every page (no codec): int64 %.2f ms, uint8 %.2f ms"
+          % (fresh_result_cost((size, size), np.int64), fresh_result_cost((size, size), np.uint8)), flush=True)
     for kind in ("smooth", "noise"):
         band64 = jpegx.synth.generate_plane(kind, size, size, seed=1, dtype=np.int64)
         for bs, band in ((1, band64.astype(np.uint8)), (1, band64), (2, band64.astype(np.uint8)), (2, band64),

@@ -4,7 +4,7 @@
 #   python profiles/summarize.py rNN_forward gpurun_out/p k_forward_fused_strip
 # Counters are collected in passes of their own (never together with a trace); the program stands directly after `--`.
 set -e
-R=${1:-gpurun_out}
+R=${1:-gpurun_out}; mkdir -p $R
 export TMPDIR=/tmp
 rm -rf $R/p_kt $R/p_fetch $R/p_write
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/p_kt -- python3 bench.py --no-cpu-baseline > $R/p_kt.json 2> $R/p_kt.err
