@@ -272,10 +272,23 @@ constexpr int jpegx_idct8_roundings(int k)
 {
     return k == 0 ? 3 : (k == 1 ? 6 : ((k == 2 || k == 3 || k == 4) ? 5 : ((k == 5 || k == 6) ? 4 : 3)));
 }
+// Round 3, second step: the weights themselves come from tests/derive_bounds.py, which runs jpegx_idct8_f32 symbolically
+// (standard model of rounding, first order): the hand count above is what it reproduces as an upper bound, the
+// derived weights are 14 percent smaller in sum (most for k or l = 4, whose constant is applied once).  Multiples of
+// 2^-12, rounded up.  The dequantisation's own roundings add dq s_k s_l.
+struct JpegxInvWeights { float w[64]; };
+constexpr JpegxInvWeights jpegx_inv_weights = {{
+    0.0937500000f, 0.2758789062f, 0.2312011719f, 0.2453613281f, 0.1770019531f, 0.2145996094f, 0.2021484375f, 0.1840820312f,
+    0.2758789062f, 0.7216796875f, 0.6230468750f, 0.6613769531f, 0.4768066406f, 0.6013183594f, 0.5664062500f, 0.5412597656f,
+    0.2312011719f, 0.6230468750f, 0.5336914062f, 0.5664062500f, 0.4084472656f, 0.5097656250f, 0.4802246094f, 0.4531250000f,
+    0.2453613281f, 0.6613769531f, 0.5664062500f, 0.6013183594f, 0.4335937500f, 0.5412597656f, 0.5097656250f, 0.4812011719f,
+    0.1770019531f, 0.4768066406f, 0.4084472656f, 0.4335937500f, 0.3125000000f, 0.3901367188f, 0.3676757812f, 0.3469238281f,
+    0.2145996094f, 0.6013183594f, 0.5097656250f, 0.5412597656f, 0.3901367188f, 0.4812011719f, 0.4531250000f, 0.4208984375f,
+    0.2021484375f, 0.5664062500f, 0.4802246094f, 0.5097656250f, 0.3676757812f, 0.4531250000f, 0.4270019531f, 0.3964843750f,
+    0.1840820312f, 0.5412597656f, 0.4531250000f, 0.4812011719f, 0.3469238281f, 0.4208984375f, 0.3964843750f, 0.3608398438f}};
 constexpr float jpegx_inv_weight(int n, int dq)   // n = k * 8 + l
 {
-    return ((n >> 3) == 0 ? 0.125f : 0.25f) * ((n & 7) == 0 ? 0.125f : 0.25f) *
-           (float)(jpegx_idct8_roundings(n >> 3) + jpegx_idct8_roundings(n & 7) + dq);
+    return jpegx_inv_weights.w[n] + ((n >> 3) == 0 ? 0.125f : 0.25f) * ((n & 7) == 0 ? 0.125f : 0.25f) * (float)dq;
 }
 JPEGX_HD float jpegx_inv_err_from_weighted_sum(float A) { return A * 0x1.004p-24f; }   // u (1 + 2^-10) A
 

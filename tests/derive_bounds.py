@@ -169,6 +169,43 @@ def idct8_aan(X):
     return x
 
 
+def idct8_plain(X):
+    """the even/odd inverse of the kernels (jpegx_idct8_f32): x = X0 / 8 + 1/4 sum_k C[k][n] X_k"""
+    q = 0.25
+    p0, p4 = mul(X[0], 0.125), mul(X[4], q * C[4])
+    g0, g1 = add(p0, p4), sub(p0, p4)
+    h0 = fma(X[6], q * C[6], mul(X[2], q * C[2]))
+    h1 = fma(X[6], -q * C[2], mul(X[2], q * C[6]))
+    E0, E1, E2, E3 = add(g0, h0), add(g1, h1), sub(g1, h1), sub(g0, h0)
+    O0 = fma(X[7], q * C[7], fma(X[5], q * C[5], fma(X[3], q * C[3], mul(X[1], q * C[1]))))
+    O1 = fma(X[7], -q * C[5], fma(X[5], -q * C[1], fma(X[3], -q * C[7], mul(X[1], q * C[3]))))
+    O2 = fma(X[7], q * C[3], fma(X[5], q * C[7], fma(X[3], -q * C[1], mul(X[1], q * C[5]))))
+    O3 = fma(X[7], -q * C[1], fma(X[5], q * C[3], fma(X[3], -q * C[5], mul(X[1], q * C[7]))))
+    x = [None] * 8
+    x[0], x[7] = add(E0, O0), sub(E0, O0)
+    x[1], x[6] = add(E1, O1), sub(E1, O1)
+    x[2], x[5] = add(E2, O2), sub(E2, O2)
+    x[3], x[4] = add(E3, O3), sub(E3, O3)
+    return x
+
+
+def inverse_plain_weights():
+    """w[k*8+l]: the weight of |d_kl| (the dequantised coefficient) in the bound u sum_kl w |d_kl| on |x32 - x64| for
+    the even/odd inverse, columns (index k) then rows (index l), without the dequantisation's own roundings (those
+    add dq s_k s_l, s_0 = 1/8, s_k = 1/4: jpegx_inv_weight)."""
+    M = true_idct()
+    one = idct8_plain(inputs(8, False))
+    A = np.array([one[n].coef for n in range(8)])
+    assert np.allclose(A, M, rtol=0, atol=1e-12)
+    E = np.array([one[n].err for n in range(8)])
+    W = np.zeros(64)
+    for k in range(8):
+        for l in range(8):
+            w2d = np.abs(A[:, l])[None, :] * E[:, k][:, None] + E[:, l][None, :] * np.abs(A[:, k])[:, None]
+            W[k * 8 + l] = w2d.max()
+    return W
+
+
 def true_idct():
     """x = Cn^T (Dinv X) = X0 / 8 + 1/4 sum_{k>=1} C[k][n] X_k (transforms.py:40-44)"""
     T = true_dct()
@@ -258,6 +295,9 @@ def main():
     print("F, generic input (ceil):", [int(math.ceil(v - 1e-9)) for v in Fg])
     _, Pp, Pg = forward_tables(dct8_plain)
     print("plain even/odd form, pixel (exact):", [round(float(v), 2) for v in Pp])
+    wp = inverse_plain_weights()
+    print("inverse (even/odd form) weights, rounded up to multiples of 2^-12:")
+    print("  ", ", ".join("%.10ff" % (math.ceil(v * 4096 - 1e-9) / 4096) for v in wp))
     h, w0, w2 = inverse_tables()
     print("inverse pre-scale h[k]:")
     print("  ", ", ".join("%.17g" % v for v in h))

@@ -16,6 +16,11 @@ static const int T_ZZ[64] = { JPEGX_TABLE_ZIGZAG8 };
 
 extern "C" {
 
+// the bound tables the kernels are compiled with (tests/test_emul.py checks them against tests/derive_bounds.py)
+float emul_aan_level_of(int n, int pixel) { return jpegx_aan_level(jpegx_aan_level_index(n, pixel != 0), pixel != 0); }
+float emul_inv_weight(int n, int dq) { return jpegx_inv_weight(n, dq); }
+double emul_aan_g(int k) { static const double G[8] = {JPEGX_AAN_G}; return G[k]; }
+
 // stats[0] = flagged coefficients, stats[1] = blocks with >=1 flag,
 // stats[2] = max over coefficients of observed |t32 - t64| / (E F / q), the kernel's per-coefficient bound
 int emul_forward(const float *in, int H, int W, int mode, double param, const float *rq32,

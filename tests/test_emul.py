@@ -198,3 +198,35 @@ def test_forward_exact_tier_share_with_the_per_coefficient_bound(emul):
     a = synth.generate_plane("noise", 512, 512, seed=9)
     _, st = run_forward(emul, a, "qtable", 0.0, 1)
     assert st[1] / (a.size / 64) < 0.03       # 3.5 % of noise blocks with the uniform 16 u S bound, ~2.3 % now
+
+
+def test_bound_tables_in_the_header_cover_the_mechanical_derivation(emul):
+    """The factors of the forward bound (15 levels per input kind), the weights of the inverse bound and the scale of
+    the AAN transform's outputs, as compiled into the kernels (csrc/jpegx_math.h), against tests/derive_bounds.py, which
+    runs the very flow graphs symbolically under the standard model of rounding: every table entry is at least what
+    the derivation gives (a level may only round UP), and not wastefully more."""
+    import derive_bounds as db
+    emul.emul_aan_level_of.restype = ctypes.c_float
+    emul.emul_inv_weight.restype = ctypes.c_float
+    emul.emul_aan_g.restype = ctypes.c_double
+    g, f_pixel, f_generic = db.forward_tables()
+    assert np.allclose([emul.emul_aan_g(k) for k in range(8)], g, rtol=1e-15)
+    assert np.allclose(AAN_G, g, rtol=1e-15)
+    for pixel, want in ((1, f_pixel), (0, f_generic)):
+        have = np.array([emul.emul_aan_level_of(n, pixel) for n in range(64)])
+        assert np.all(have >= want - 1e-6), (pixel, np.argmax(want - have))
+        assert np.all(have <= want * 1.35 + 1e-6)                       # 15 levels for 64 factors: little is given away
+    w = db.inverse_plain_weights()
+    have = np.array([emul.emul_inv_weight(n, 0) for n in range(64)])
+    assert np.all(have >= w - 1e-9) and np.all(have <= w + 2.0 ** -12 + 1e-9)
+    s = np.array([0.125 if k == 0 else 0.25 for k in range(8)])
+    have2 = np.array([emul.emul_inv_weight(n, 2) for n in range(64)])
+    assert np.allclose(have2 - have, 2 * np.outer(s, s).ravel(), atol=1e-7)
+    # the hand-counted roundings of rounds 1-2 (jpegx_fwd_roundings / jpegx_idct8_roundings) were upper bounds of the same
+    _, plain_pixel, plain_generic = db.forward_tables(db.dct8_plain)
+
+    def hand(n, pix):
+        def r(k, ex):
+            return (0 if ex else 3) if k == 0 else ((5 if ex else 6) if k & 1 else ((2 if ex else 5) if k == 4 else (3 if ex else 5)))
+        return r(n & 7, pix) + r(n >> 3, pix and (n & 7) == 0) + 1
+    assert all(hand(n, True) >= plain_pixel[n] - 1e-9 and hand(n, False) >= plain_generic[n] - 1e-9 for n in range(64))
