@@ -19,10 +19,15 @@ void enqueue_phase2(const uint8_t *d_bytes, size_t nbytes, long long nblocks, vo
 // segment tables do not fit (handed back: run phase 1 / phase 2 above).
 struct SegPlan {
     int seg, cmax, levels;      // bytes per segment, candidates a segment's tables hold, doubling levels
+    int span_cap;               // LDS bytes the block decoder has for the bytes of a tile's 64 blocks
     unsigned nseg;
-    size_t ws_bytes;
-    bool ok;                    // false: stream too long for this scheme (> 64 K segments)
+    size_t ws_bytes, state_bytes;   // scratch; the persistent state (status blocks + exit words)
+    bool ok;                    // false: stream too long for this scheme
 };
 SegPlan seg_plan(size_t nbytes, long long nblocks);
-void enqueue_segmented(const uint8_t *d_bytes, size_t nbytes, long long nblocks, const SegPlan &plan, void *d_ws, int16_t *d_zz, hipStream_t st);
+// d_state: state_cap >= plan.state_bytes bytes that only this scheme touches -- fresh: never used before (it is cleared whole, once;
+// afterwards every call leaves it clean); parity alternates from call to call on one d_state (the call's status words are at
+// d_state + 64 * parity).  d_ws: plan.ws_bytes of scratch.
+void enqueue_segmented(const uint8_t *d_bytes, size_t nbytes, long long nblocks, const SegPlan &plan, void *d_state, size_t state_cap, bool fresh, int parity,
+                       void *d_ws, int16_t *d_zz, hipStream_t st);
 }  // namespace jpegx_decode

@@ -21,6 +21,7 @@
 // always writes zero padding (rle_byte_stream.py:55-56).  tests/test_gpu_entropy.py fuzzes both decoders.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/jpegx.h"
 #include "jpegx_entropy_decode.h"
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(256) void k_dec_scatter(const unsigned char *__rest
 // least 16 readable bytes longer than the stream.
 template <bool WRITE>
 __device__ __forceinline__ unsigned parse_block(const unsigned *__restrict__ words, unsigned long long nbits, unsigned p,
-                                                unsigned char *tile, int row)
+                                                unsigned char *tile, int row, int linear_stride = 0)   // 0: the swizzled tile; else bytes per plain row
 {
     const unsigned long long left = nbits - (unsigned long long)p * 8u;
     const unsigned *wp = words + (p >> 2);
@@ -156,7 +157,8 @@ __device__ __forceinline__ unsigned parse_block(const unsigned *__restrict__ wor
             const unsigned bits = (w << 8) >> (32 - size);
             const unsigned mag = bits & ((1u << (size - 1)) - 1u);
             const int amp = (bits >> (size - 1)) ? (int)mag : -(int)mag;                    // sign bit '1' = positive
-            *reinterpret_cast<int16_t *>(tile + tile_off(row, (int)(nn >> 3)) + (nn & 7u) * 2) = (int16_t)amp;
+            unsigned char *at = linear_stride ? tile + row * linear_stride + nn * 2u : tile + tile_off(row, (int)(nn >> 3)) + (nn & 7u) * 2;
+            *reinterpret_cast<int16_t *>(at) = (int16_t)amp;
         }
         if (bad | eob) {
             ret = bad ? NIL : p + ((pos - first + 8 + 7) >> 3);
@@ -256,338 +258,664 @@ __global__ __launch_bounds__(64) void k_dec_blocks(const unsigned *__restrict__ 
     dec_blocks_body(words, nbytes, start_pos, nblk, out, head);
 }
 
-// the same behind the segmented scheme: nothing to decode when that refused the stream or handed it back
-__global__ __launch_bounds__(64) void k_dec_blocks_guarded(const unsigned *__restrict__ words, size_t nbytes, const unsigned *__restrict__ start_pos,
-                                                           int nblk, int16_t *__restrict__ out, unsigned *__restrict__ head)
-{
-    if (head[1] != 0 || head[2] != 0) return;
-    dec_blocks_body(words, nbytes, start_pos, nblk, out, head);
-}
-
 // ================================================================================================
-// Round 3: block starts by SEGMENTS, five launches instead of fourteen and no host round trip.
+// Round 3: block starts by SEGMENTS, blocks decoded from LDS by four lanes each -- three launches, no host round trip.
 //
 // The pointer-jumping scheme above works on the whole stream at once: candidate compaction (3 launches), one
 // parse per candidate with a binary search in global memory for the candidate behind it, log4(blocks) jump
-// passes (8 launches for a 4096 x 4096 band, each a few microseconds of work) and a host read-back of the
-// candidate count in the middle.  What it does not use: a block is at most 185 bytes long, so everything about a
-// stretch of the stream can be resolved LOCALLY, in LDS, except which of a handful of candidates the chain of true
-// blocks enters the stretch at.
-//   k_seg_parse   one workgroup per segment of `seg` bytes: the segment (+ 256 bytes) into LDS, its candidates
-//                 compacted in order, one parse per candidate from LDS (the candidate behind it found by a binary
-//                 search in LDS), pointer doubling IN LDS.  For every candidate in the first 192 bytes -- the only
-//                 places the chain can enter at -- where the chain leaves the segment and how many blocks it passes.
-//   k_seg_entries which entry each segment is really entered at.  Chains merge within a block or two, so for almost
-//                 every segment all entries agree on the exit (a "constant" segment) and the entry of the next one
-//                 is known without looking further back; a thread walks back to the nearest constant segment
-//                 (bounded) and forward again.
-//   k_seg_scan    block index of every segment's first block (scan), and the proof: the chain from position 0,
-//                 segment by segment, is exactly the entries chosen (so the shortcut above can only cost time, never
-//                 correctness), ends at the stream's last byte and holds the plane's number of blocks.
-//   k_seg_starts  the segment's doubling tables again (from the persisted first level), block i's start position.
-//   k_dec_blocks  as before.
-// A stream this layout does not fit (more candidates in a segment than its tables hold: a quarter of its bytes
-// zero; more than 64 K segments) raises a flag and the host falls back to the scheme above.
+// passes (8 launches for a 4096 x 4096 band), a host read-back of the candidate count in the middle, and a
+// parse of every block straight from global memory (one dependent load per dword of the block: latency bound).
+// What it does not use: a block is at most 185 bytes long, so everything about a stretch of the stream can be
+// resolved LOCALLY, in LDS, except which of a handful of candidates the chain of true blocks enters the stretch
+// at -- and that is 16 bits the segment in front can hand over.
+//
+// k_seg_starts, one wave per segment of `seg` bytes (about 46 candidates: one parse pass of the wave's 64 lanes):
+//   1. the segment (+ 16 bytes in front, + 208 behind: the longest block and the bit reader's look-ahead) into LDS
+//      as big-endian dwords; candidates = position 0 and every position behind a 0x00 byte, compacted in order;
+//   2. ONE parse per candidate from LDS, three codes per step, leaving way marks (where the walk stands after 15, 30,
+//      45 codes); J[0][c] = the candidate the block at c ends at | EXIT + position in the next segment | END |
+//      INVALID; binary lifting in LDS: J[k][c] = the candidate 2^k blocks on;
+//   3. candidates within the first 192 bytes are the only places the chain can enter at.  Chains merge within a
+//      block or two, so for almost every segment all entries agree on the exit: that exit is PUBLISHED AT ONCE
+//      (one 4-byte agent-scope store), before the segment knows its own entry;
+//   4. the segment reads the exit of the segment in front (a relaxed agent-scope poll; the only wait in the scheme,
+//      for a neighbour that started at the same moment), which names its entry, hence its number of blocks;
+//   5. block r of the segment is the candidate r steps from the entry: byte position + way marks -> prov[s][r],
+//      the count -> C[s].  Nothing here needs the block's index in the plane.
+// k_seg_scan, one workgroup: exclusive scan of the counts (first block index of every segment), the segment every
+// 64th block lies in, and the check that the stream holds the plane's number of blocks.
+// k_dec_blocks_lds, one workgroup of four waves per 64 blocks: the blocks' bytes (one contiguous span of the stream)
+// into LDS with 16-byte loads, wave p decodes every block from its p-th way mark to the next into the block's row
+// of an LDS tile, and the tile leaves as 1 KiB stores.
+// Built and measured on the way (profiles/r03_decode_designs.txt): ONE launch with a decoupled look-back for the
+// block indices and the blocks decoded speculatively while they are parsed (the tile quadruples the LDS per wave,
+// 9 waves per CU then sit in the look-back's waits, half of the decoding is for false candidates: 125-190 us); an
+// atomic ticket instead of the workgroup index (one word hands out ~88 tickets per microsecond: +45 us); the block
+// indices by a last-arriver per group of 64 segments (its scatter is the kernel's tail: +30 us); grids cut to what
+// the chip holds at once, every wave walking through several segments (no gain: 47 against 46 us, and the loop's
+// scalar registers cost three waves per CU).
+// The stream is read twice; what reaches global memory is 16 bytes per block and 8 per segment.  Every spin is
+// bounded; a wave that gives up poisons the segments behind it and the host takes the scheme above (also for a
+// segment with more candidates than the tables hold).  Everything the chain is made of is derived from the exit in
+// front, so the early publication can only ever be wrong for a stream that is refused anyway (its entry turns out
+// INVALID).
 // ================================================================================================
 namespace seg {
 
-constexpr int THREADS = 128;              // two waves per segment: its ~60-200 candidates fill one or two, more would idle
+typedef __attribute__((address_space(1))) unsigned gu32;
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+#define JPEGX_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+
 constexpr int REACH = 192;                 // a block is at most 185 bytes: the chain enters a segment within its first REACH bytes
-constexpr int EMAX = REACH + 1;
-constexpr unsigned INVALID = 0xFFFFu, END = 0xFFFEu, EXIT = 0x8000u;   // EXIT | position relative to the NEXT segment
-constexpr unsigned AFTER = 0xFFFDu;        // entry of a segment behind the stream's last block (a short tail segment)
-__device__ __forceinline__ bool is_exit(unsigned x) { return (x & EXIT) != 0 && x < AFTER; }
-constexpr int WALK_LIMIT = 64;
+constexpr int ROW = 144;                   // bytes per tile row (128 + 16: rows stay 16-byte aligned, the bank pattern of a column of rows spreads)
+constexpr int FRONT = 16, TAIL = 208;      // window bytes in front of / behind the segment
+constexpr unsigned INVALID = 0xFFFFu, END = 0xFFFEu, AFTER = 0xFFFDu, POISON = 0xFFFCu, EXIT = 0x8000u;   // EXIT | position in the NEXT segment
+constexpr unsigned TAG = 0x10000u;         // set in every published exit word (0 = not there yet)
+constexpr unsigned SPIN_LIMIT = 1u << 18;  // polls (each behind an s_sleep) before a wave gives the stream back
+__device__ __forceinline__ bool is_exit(unsigned x) { return (x & EXIT) != 0 && x < POISON; }
 
 struct Ws {
-    unsigned *head;        // [1] error bits, [2] fallback bits, [3] blocks found
-    unsigned *ncand, *nent, *konst, *entry, *count, *first;    // per segment
-    unsigned short *pos, *j0;                                   // [nseg][cmax]
-    unsigned short *ent_exit, *ent_cnt;                         // [nseg][EMAX]
-    unsigned *start_pos;                                        // [nblocks]
+    unsigned *head;              // [1] error bits, [2] fallback bits, [3] blocks found
+    unsigned *next_head;         // the next call's status block (the block decoder leaves it zero)
+    unsigned *E;                 // [nseg] TAG | exit code; zero between calls (the block decoder sees to that)
+    unsigned *C;                 // [nseg] the segment's blocks
+    unsigned *F;                 // [nseg + 1] index of the segment's first block (k_seg_scan)
+    unsigned *wave_seg;          // [ceil(nblocks / 64)] the segment that holds block 64 w (k_seg_scan)
+    u32x4 *prov;                 // [nseg][cmax] the segment's blocks: byte position, three way marks (bit offset << 8 | coefficients so far, 0 = none)
+    unsigned long long *trace;   // -DJPEGX_DECODE_STATS builds: [nseg][16] time stamps
 };
 
 __host__ __device__ inline size_t up16(size_t v) { return (v + 15) & ~(size_t)15; }
 
-__host__ __device__ inline Ws carve(void *base, unsigned nseg, int cmax, long long nblocks, size_t *total = nullptr)
+// state: two status blocks (alternate calls) and the exit words -- zero between calls, in an allocation of their own (the
+// other arrays' places depend on the segment count: a short stream's arrays would lie in a long stream's exit words);
+// scratch: everything that is written before it is read
+__host__ __device__ inline Ws carve(void *state, void *scratch, unsigned nseg, int cmax, long long nblocks, int parity, size_t *scratch_bytes = nullptr,
+                                    size_t *state_bytes = nullptr)
 {
-    unsigned char *p = static_cast<unsigned char *>(base);
-    size_t o = 16;
+    unsigned char *q = static_cast<unsigned char *>(state), *p = static_cast<unsigned char *>(scratch);
     Ws w;
-    w.head = reinterpret_cast<unsigned *>(p);
-    unsigned **per[] = {&w.ncand, &w.nent, &w.konst, &w.entry, &w.count, &w.first};
-    for (unsigned **q : per) { *q = reinterpret_cast<unsigned *>(p + o); o += up16((size_t)nseg * 4); }
-    w.pos = reinterpret_cast<unsigned short *>(p + o); o += up16((size_t)nseg * cmax * 2);
-    w.j0 = reinterpret_cast<unsigned short *>(p + o); o += up16((size_t)nseg * cmax * 2);
-    w.ent_exit = reinterpret_cast<unsigned short *>(p + o); o += up16((size_t)nseg * EMAX * 2);
-    w.ent_cnt = reinterpret_cast<unsigned short *>(p + o); o += up16((size_t)nseg * EMAX * 2);
-    w.start_pos = reinterpret_cast<unsigned *>(p + o); o += up16((size_t)nblocks * 4);
-    if (total) *total = o;
+    w.head = reinterpret_cast<unsigned *>(q + 64 * parity);
+    w.next_head = reinterpret_cast<unsigned *>(q + 64 * (1 - parity));
+    w.E = reinterpret_cast<unsigned *>(q + 128);
+    if (state_bytes) *state_bytes = 128 + up16((size_t)nseg * 4);
+    size_t o = 0;
+    w.C = reinterpret_cast<unsigned *>(p + o); o += up16((size_t)nseg * 4 + 64);      // read in 16-byte pieces
+    w.F = reinterpret_cast<unsigned *>(p + o); o += up16(((size_t)nseg + 1) * 4);
+    w.wave_seg = reinterpret_cast<unsigned *>(p + o); o += up16((size_t)((nblocks + 63) / 64) * 4);
+    w.prov = reinterpret_cast<u32x4 *>(p + o); o += up16((size_t)nseg * cmax * 16);
+    w.trace = reinterpret_cast<unsigned long long *>(p + o);
+#ifdef JPEGX_DECODE_STATS
+    o += 64 + (size_t)nseg * 128;
+#endif
+    if (scratch_bytes) *scratch_bytes = o;
     return w;
 }
 
-// workgroup-wide exclusive scan of one value per thread; returns the exclusive prefix, *total = sum
-__device__ __forceinline__ unsigned block_scan(unsigned v, unsigned *s_part, unsigned *total)
+__host__ __device__ inline int levels_of(int cmax)          // 2^levels = cmax: chains inside a segment are shorter than that
 {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    unsigned incl = v;
+    int l = 0;
+    while ((1 << l) < cmax) ++l;
+    return l;
+}
+
+__host__ __device__ inline size_t dec_lds_bytes(int span_cap) { return (size_t)span_cap + 64 * ROW + 1024 + 288; }
+
+__host__ __device__ inline size_t lds_bytes(int seg, int cmax)
+{
+    return (size_t)(FRONT + seg + TAIL) + 64 * 16 + 256 + (size_t)cmax * 2 * (1 + levels_of(cmax));
+}
+
+constexpr int MARK_STEPS = 5;               // steps of three codes between two way marks
+
+// by how much a code advances the coefficient counter, from its header byte: run + 1 for an amplitude code, 15 for the
+// chain code 1111 0000 (FIFTEEN zeros, util.py:134-154), 128 -- beyond any block -- for everything a block cannot go
+// on with: the end marker, a zero size with another run, size 1 (a sign without amplitude bits: the reference's
+// decode_signed fails on it, rle_byte_stream.py:35-42).  Lane l fills entries 4l .. 4l + 3.
+__device__ __forceinline__ void fill_advance_table(unsigned char *tab, int lane)
+{
+    unsigned packed = 0;
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const unsigned u = __shfl_up(incl, d);
-        if (lane >= d) incl += u;
+    for (int j = 0; j < 4; ++j) {
+        const unsigned h = (unsigned)lane * 4u + j, size = h & 15u, run = h >> 4;
+        const unsigned inc = size >= 2u ? run + 1u : (h == 0xF0u ? 15u : 128u);
+        packed |= inc << (8 * j);
     }
-    if (lane == 63) s_part[wv] = incl;
-    __syncthreads();
-    unsigned base = 0;
-    for (int k = 0; k < wv; ++k) base += s_part[k];
-    unsigned sum = 0;
-    for (int k = 0; k < THREADS / 64; ++k) sum += s_part[k];
-    *total = sum;
-    __syncthreads();
-    return base + incl - v;
+    reinterpret_cast<unsigned *>(tab)[lane] = packed;
 }
 
-// index of position `e` in the sorted list pos[lo, hi), or -1
-__device__ __forceinline__ int find_pos(const unsigned short *pos, int lo, int hi, unsigned e)
+// Where the block at bit position q of a window of big-endian dwords ends (BYTE position), or NIL if what is there is
+// not a block -- no coefficients wanted.  Every lane walks its own candidate, 63 dependent codes on noise, and a wave's
+// time in this loop is the latency of a step times the steps, whatever else runs on the CU.  So a step takes THREE codes:
+// the 64 bits at q (three dwords) hold the first header and -- a code is at most 23 bits long -- the two behind it; all
+// go through the table above, and ONE comparison each (a 65th coefficient) ends the walk for every reason there is.  A
+// lane that has stopped keeps its q, pointing at the code that stopped it; what that was is looked at once, behind the
+// loop.  The window holds zeros behind the stream's end, so a walk that runs over it meets an end marker there and is
+// refused by position.
+__device__ __forceinline__ unsigned parse_tab(const unsigned *sw, const unsigned char *tab, const unsigned q0, unsigned end_bits, bool live,
+                                              unsigned (&mark)[3])
 {
-    const int end = hi;
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (pos[mid] < e) lo = mid + 1; else hi = mid;
+    unsigned n = 0, q = q0;
+    mark[0] = mark[1] = mark[2] = 0u;
+    for (int it = 1; __any(live); ++it) {
+        const unsigned wi = q >> 5, sh = q & 31u;
+        const unsigned d0 = sw[wi], d1 = sw[wi + 1], d2 = sw[wi + 2];
+        const unsigned w = (unsigned)(((((unsigned long long)d0 << 32) | d1) << sh) >> 32);     // bits q .. q + 31
+        const unsigned x = (unsigned)(((((unsigned long long)d1 << 32) | d2) << sh) >> 32);     // bits q + 32 .. q + 63
+        const unsigned h1 = w >> 24, a1 = 8u + (h1 & 15u);
+        const unsigned v = (unsigned)(((((unsigned long long)w << 32) | x) << a1) >> 32);       // bits from the second code on (a1 <= 23)
+        const unsigned h2 = v >> 24, a2 = 8u + (h2 & 15u);
+        const unsigned h3 = (v << a2) >> 24, a3 = 8u + (h3 & 15u);                              // a2 <= 23: the third header lies inside v
+        const unsigned n1 = n + tab[h1], n2 = n1 + tab[h2], n3 = n2 + tab[h3];
+        const bool go1 = live && n1 <= 64u, go2 = go1 && n2 <= 64u;
+        live = go2 && n3 <= 64u;
+        q += (go1 ? a1 : 0u) + (go2 ? a2 : 0u) + (live ? a3 : 0u);
+        n = n3;
+        // way marks for the block decoder: where the walk stands after 15, 30 and 45 codes (bit offset into the block and
+        // coefficients so far), if it goes on from there -- four lanes can then share a block
+        if (it == MARK_STEPS || it == 2 * MARK_STEPS || it == 3 * MARK_STEPS)
+            mark[it / MARK_STEPS - 1] = live ? ((q - q0) << 8) | n : 0u;
     }
-    return (lo < end && pos[lo] == e) ? lo : -1;
+    const unsigned wi = q >> 5;
+    const unsigned w = (unsigned)(((((unsigned long long)sw[wi] << 32) | sw[wi + 1]) << (q & 31u)) >> 32);
+    return ((w >> 24) == 0u && q + 8u <= end_bits) ? (q + 15u) >> 3 : NIL;   // an end marker (+ the zero padding) inside the stream
 }
 
-// J[k][c] = the candidate 2^k blocks behind c, or the terminal code the chain meets before that
-__device__ __forceinline__ void double_up(unsigned short *J, int cmax, int levels, int n)
+// The walk WITH the coefficients, into `row` (64 int16, zero beforehand), for the block decoder: from bit position q with n
+// coefficients behind it, up to the way mark q_stop (or to what ends the block).  No table here (the counter's advance is
+// arithmetic: run + 1 for an amplitude code, 15 for the chain code, 128 for what ends or breaks a block), two codes per
+// step, from the 64 bits at q (three dwords).  Stores go by address select (`dummy` when the code carries no amplitude
+// or the lane has stopped), not under a branch.
+__device__ __forceinline__ unsigned parse_coefficients(const unsigned *sw, unsigned q, unsigned n, const unsigned q_stop, unsigned char *row,
+                                                       unsigned char *dummy, bool live)
 {
-    for (int k = 1; k < levels; ++k) {
-        const unsigned short *prev = J + (size_t)(k - 1) * cmax;
-        unsigned short *cur = J + (size_t)k * cmax;
-        for (int c = threadIdx.x; c < n; c += THREADS) {
-            const unsigned a = prev[c];
-            cur[c] = (unsigned short)(a < EXIT ? prev[a] : a);
-        }
-        __syncthreads();
+    auto advance = [](unsigned h) -> unsigned { return (h & 15u) >= 2u ? (h >> 4) + 1u : (h == 0xF0u ? 15u : 128u); };
+    auto amplitude = [](unsigned w, unsigned size) -> int {
+        const unsigned mag = __builtin_amdgcn_ubfe(w, 24u - size, size - 1u);
+        return (w & 0x00800000u) ? (int)mag : -(int)mag;                     // sign bit '1' = positive
+    };
+    while (__any(live)) {
+        const unsigned wi = q >> 5, sh = q & 31u;
+        const unsigned d0 = sw[wi], d1 = sw[wi + 1], d2 = sw[wi + 2];
+        const unsigned w1 = (unsigned)(((((unsigned long long)d0 << 32) | d1) << sh) >> 32);
+        const unsigned x1 = (unsigned)(((((unsigned long long)d1 << 32) | d2) << sh) >> 32);
+        const unsigned h1 = w1 >> 24, s1 = h1 & 15u, q1 = q + 8u + s1;
+        const unsigned w2 = (unsigned)(((((unsigned long long)w1 << 32) | x1) << (8u + s1)) >> 32);
+        const unsigned h2 = w2 >> 24, s2 = h2 & 15u, q2 = q1 + 8u + s2;
+        const unsigned n1 = n + advance(h1), n2 = n1 + advance(h2);
+        const bool go1 = live && n1 <= 64u;
+        const bool go2 = go1 && q1 < q_stop && n2 <= 64u;
+        *reinterpret_cast<int16_t *>((go1 && s1 >= 2u) ? row + (n1 - 1u) * 2u : dummy) = (int16_t)amplitude(w1, s1);
+        *reinterpret_cast<int16_t *>((go2 && s2 >= 2u) ? row + (n2 - 1u) * 2u : dummy) = (int16_t)amplitude(w2, s2);
+        q = go2 ? q2 : (go1 ? q1 : q);
+        n = go2 ? n2 : n1;
+        live = go2 && q < q_stop;
     }
+    return q;       // the code the walk stopped in front of: the way mark it was told, or what ends the block
 }
 
-__global__ __launch_bounds__(THREADS) void k_seg_parse(const unsigned char *__restrict__ bytes, size_t nbytes, int seg, int cmax, int levels,
-                                                       unsigned nseg, void *ws, long long nblocks)
+// workgroup i (it runs on XCD i % 8) -> segment: the XCDs take turns in runs of 32 segments
+constexpr int RUN_LOG = 5;
+__device__ __forceinline__ unsigned xcd_run_segment(unsigned i)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
-    __shared__ unsigned s_part[4];
-    __shared__ unsigned short s_exit[EMAX];
-    const Ws W = carve(ws, nseg, cmax, nblocks);
-    const int wwords = (seg + 264) / 4;                    // window: bytes [base - 4, base + seg + 260)
-    unsigned *sw = reinterpret_cast<unsigned *>(sm);
-    unsigned short *cpos = reinterpret_cast<unsigned short *>(sm + (size_t)wwords * 4);
-    unsigned short *J = cpos + cmax;
-    const unsigned s = blockIdx.x;
-    const int t = threadIdx.x;
-    const size_t base = (size_t)s * seg;
-    const size_t readable = (nbytes + 16) & ~(size_t)3;     // the buffer carries at least 16 zero bytes behind the stream
-    for (int i = t; i < wwords; i += THREADS) {
-        const long long off = (long long)base - 4 + 4LL * i;
-        unsigned v = 0;
-        if (off >= 0 && (size_t)off + 4 <= readable) v = *reinterpret_cast<const unsigned *>(bytes + off);
-        sw[i] = v;
-    }
-    __syncthreads();
-    // candidates in stream order: position 0, and every position behind a 0x00 byte
-    const unsigned char *sb = sm + 4;                        // sb[p] = byte at position base + p; sb[-1] is readable
-    const int per = seg / THREADS;                           // <= 64 (seg <= 8192)
-    unsigned long long mask = 0;
-    for (int i = 0; i < per; ++i) {
-        const int p = t * per + i;
-        const bool c = base + p < nbytes && (base + p == 0 || sb[p - 1] == 0);
-        mask |= (unsigned long long)c << i;
-    }
-    unsigned total = 0;
-    unsigned at = block_scan((unsigned)__popcll(mask), s_part, &total);
-    if (total > (unsigned)cmax || total == 0) {
-        // more zero bytes than the tables hold: the general scheme decides.  None at all: only the tail of the last
-        // block can look like that (k_seg_scan checks that nothing tries to enter here)
-        if (t == 0) {
-            if (total) atomicOr(&W.head[2], 1u);
-            W.ncand[s] = 0; W.nent[s] = 0; W.konst[s] = INVALID;
-        }
-        return;
-    }
-    while (mask) {
-        const int i = __ffsll((long long)mask) - 1;
-        mask &= mask - 1;
-        cpos[at++] = (unsigned short)(t * per + i);
-    }
-    __syncthreads();
-    // one parse per candidate, from LDS
-    const unsigned long long win_bits = (unsigned long long)(nbytes - base + 4) * 8u;
-    for (unsigned c = t; c < total; c += THREADS) {
-        const unsigned p = cpos[c];
-        const unsigned e = parse_block<false>(sw, win_bits, p + 4, nullptr, 0);
-        unsigned code = INVALID;
-        if (e != NIL) {
-            const unsigned er = e - 4;
-            if (base + er == nbytes) code = END;
-            else if (er >= (unsigned)seg) code = EXIT | (er - (unsigned)seg);
-            else {
-                const int i = find_pos(cpos, (int)c + 1, (int)total, er);
-                code = i < 0 ? INVALID : (unsigned)i;
+    const unsigned j = i >> 3, x = i & 7u;
+    return ((((j >> RUN_LOG) << 3) + x) << RUN_LOG) + (j & ((1u << RUN_LOG) - 1u));
+}
+
+__device__ __forceinline__ unsigned wave_sum(unsigned v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    return v;
+}
+
+// 16-byte pieces [first, first + n) of the stream -> LDS as big-endian dwords, up to PER pieces per thread, all loads in flight at once
+template <int PER, int THREADS = 64>
+__device__ __forceinline__ void stage_pieces(const unsigned char *__restrict__ bytes, size_t nbytes, long long first_off, int npieces,
+                                             unsigned char *sm, int lane)
+{
+    const size_t readable = (nbytes + 16) & ~(size_t)3;                        // the buffer carries 16 bytes behind the stream
+    u32x4 v[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int i = lane + THREADS * k;
+        const long long off = first_off + 16LL * i;
+        v[k] = u32x4{0u, 0u, 0u, 0u};
+        if (i < npieces) {
+            if (off >= 0 && (size_t)off + 16 <= readable) {
+                v[k] = *reinterpret_cast<const u32x4 *>(bytes + off);
+            } else {
+                unsigned t[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const long long o = off + 4 * j;
+                    if (o >= 0 && (size_t)o + 4 <= readable) t[j] = *reinterpret_cast<const unsigned *>(bytes + o);
+                }
+                v[k] = u32x4{t[0], t[1], t[2], t[3]};
             }
         }
-        J[c] = (unsigned short)code;
     }
-    __syncthreads();
-    for (unsigned c = t; c < total; c += THREADS) {          // the first level and the positions stay for k_seg_starts
-        W.pos[(size_t)s * cmax + c] = cpos[c];
-        W.j0[(size_t)s * cmax + c] = J[c];
-    }
-    double_up(J, cmax, levels, (int)total);
-    // where the chain leaves, and after how many blocks, from every candidate it can enter at
-    unsigned nent = 0;
-    {
-        int lo = 0, hi = (int)total;
-        while (lo < hi) { const int mid = (lo + hi) >> 1; if (cpos[mid] <= REACH) lo = mid + 1; else hi = mid; }
-        nent = (unsigned)lo;
-    }
-    for (unsigned j = t; j < nent; j += THREADS) {
-        unsigned cur = j, cnt = 0;
-        for (int k = levels - 1; k >= 0; --k) {
-            const unsigned n = J[(size_t)k * cmax + cur];
-            if (n < EXIT) { cur = n; cnt += 1u << k; }
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int i = lane + THREADS * k;
+        if (i < npieces) {
+            u32x4 b = v[k];
+            b.x = __builtin_bswap32(b.x); b.y = __builtin_bswap32(b.y); b.z = __builtin_bswap32(b.z); b.w = __builtin_bswap32(b.w);
+            *reinterpret_cast<u32x4 *>(sm + 16 * i) = b;
         }
-        const unsigned fin = J[cur];
-        s_exit[j] = (unsigned short)fin;
-        W.ent_exit[(size_t)s * EMAX + j] = (unsigned short)fin;
-        W.ent_cnt[(size_t)s * EMAX + j] = (unsigned short)(cnt + 1);
-    }
-    __syncthreads();
-    if (t == 0) {
-        unsigned k = INVALID;                                // the common exit of all entries that have one, else INVALID
-        bool same = true;
-        for (unsigned j = 0; j < nent; ++j) {
-            const unsigned x = s_exit[j];
-            if (x == INVALID) continue;
-            if (k == INVALID) k = x; else if (k != x) same = false;
-        }
-        W.ncand[s] = total;
-        W.nent[s] = nent;
-        W.konst[s] = same ? k : INVALID;
     }
 }
 
-// entry (candidate index) of segment s given the position `rel` the chain arrives at, or -1
-__device__ __forceinline__ int entry_of(const Ws &W, unsigned s, int cmax, unsigned rel)
+__global__ __launch_bounds__(64) void k_seg_starts(const unsigned char *__restrict__ bytes, size_t nbytes, int seg, int cmax, unsigned nseg,
+                                                   void *state, void *ws, long long nblocks, int parity)
 {
-    return find_pos(W.pos + (size_t)s * cmax, 0, (int)W.nent[s], rel);
-}
-
-__global__ __launch_bounds__(THREADS) void k_seg_entries(unsigned nseg, int cmax, void *ws, long long nblocks)
-{
-    const Ws W = carve(ws, nseg, cmax, nblocks);
-    const unsigned s = blockIdx.x * THREADS + threadIdx.x;
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+    const Ws W = carve(state, ws, nseg, cmax, nblocks, parity);
+    gu32 *gE = (gu32 *)W.E;
+    gu32 *ghead = (gu32 *)W.head;
+    const int lane = threadIdx.x;
+    // Segment = workgroup index.  A wave waits only for lower-numbered segments; the workgroups of a grid are handed to
+    // the compute units in increasing order (each XCD its share), so the lowest-numbered unfinished one is always
+    // running and the waits end.  HIP does not promise that order: should it ever not hold, the bounded spins below
+    // run out, the waves poison what is behind them and the host takes the general scheme -- slower, never wrong.
+    // (An atomic ticket would make the order a fact, but one word hands out only ~88 tickets per microsecond:
+    // 130 us for the 11 000 segments of a 4096 x 4096 noise band, several times the rest of the kernel.)
+    // The XCDs take turns in runs of 32 waves (workgroup i runs on XCD i % 8 and each XCD starts its share in order): a
+    // wave and the one in front are then neighbours in ONE XCD's order, started back to back, except at a run's first
+    // wave.  With the natural numbering neighbours sit on different XCDs, and whenever those are a round apart a wave
+    // waits a whole round for the exit in front, holding its LDS (measured: waits of 20-40 us, +40 %).
+    const unsigned s = xcd_run_segment(blockIdx.x);                            // the grid is padded to whole runs
     if (s >= nseg) return;
-    unsigned entry = INVALID, count = 0;
-    if (s == 0) {
-        entry = W.nent[0] > 0 ? 0u : INVALID;               // position 0 is candidate 0 of segment 0
-    } else {
-        // nearest segment below whose exit does not depend on its entry (or segment 0, whose entry is known)
-        unsigned tq = s - 1;
-        int steps = 0;
-        while (tq > 0 && W.konst[tq] == INVALID && steps < WALK_LIMIT) { --tq; ++steps; }
-        unsigned x;                                           // what the chain leaves segment tq with
-        if (W.konst[tq] != INVALID) x = W.konst[tq];
-        else if (tq == 0 && W.nent[0] > 0) x = W.ent_exit[0];
-        else { atomicOr(&W.head[2], 4u); x = INVALID; }
-        for (unsigned u = tq + 1; u <= s && x != INVALID; ++u) {
-            if (x == END || x == AFTER) { x = AFTER; if (u == s) entry = AFTER; continue; }
-            const int j = is_exit(x) ? entry_of(W, u, cmax, x & 0x7FFFu) : -1;
-            if (j < 0) break;
-            if (u == s) entry = (unsigned)j; else x = W.ent_exit[(size_t)u * EMAX + j];
+#ifdef JPEGX_DECODE_STATS
+    unsigned long long *trace = W.trace + 8 + (size_t)s * 16; // time stamps (100 MHz): slot 0 = start, k + 1 = end of phase k
+    if (lane == 0) trace[0] = wall_clock64();
+    if (lane == 0 && s == 0) { unsigned *info = reinterpret_cast<unsigned *>(W.trace); info[4] = nseg; info[5] = (unsigned)seg; info[6] = (unsigned)cmax; info[7] = (unsigned)nblocks; }
+#define JPEGX_PHASE(k) do { if (lane == 0) trace[(k) + 1] = wall_clock64(); } while (0)
+#else
+#define JPEGX_PHASE(k) do { } while (0)
+#endif
+    const int win = FRONT + seg + TAIL;
+    const int levels = levels_of(cmax);
+    unsigned *sw = reinterpret_cast<unsigned *>(sm);
+    u32x4 *rec = reinterpret_cast<u32x4 *>(sm + win);                          // per lane: candidate mask (64 bit), candidates in front
+    unsigned char *tab = reinterpret_cast<unsigned char *>(rec + 64);
+    unsigned short *cpos = reinterpret_cast<unsigned short *>(tab + 256);
+    unsigned short *J = cpos + cmax;                                           // [levels][cmax]: the candidate 2^k blocks on, or a terminal code
+
+    // ---- 1. the window
+    const size_t base = (size_t)s * seg;
+    stage_pieces<5>(bytes, nbytes, (long long)base - FRONT, win / 16, sm, lane);     // (16 + 4096 + 208) / 16 / 64 < 5 pieces per lane
+    fill_advance_table(tab, lane);
+    __syncthreads();
+    JPEGX_PHASE(0);
+
+    // candidates: position 0 of the stream, and every position behind a 0x00 byte
+    const int stretch = seg >> 6;                                              // bytes per lane: a multiple of 4, at most 64
+    const unsigned inv = ((1u << 20) + (unsigned)stretch - 1u) / (unsigned)stretch;
+    const int p0 = lane * stretch;
+    unsigned long long m;
+    {
+        const unsigned *swl = reinterpret_cast<const unsigned *>(sm + FRONT + p0);
+        unsigned long long z = 0;                                              // bit j: byte p0 + j is zero
+        for (int k = 0; k < (stretch >> 2); ++k) {
+            const unsigned x = swl[k];
+            const unsigned t = (~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu)) >> 7;   // bits 24, 16, 8, 0 <-> bytes 0..3
+            z |= (unsigned long long)(((t * 0x08040201u) >> 24) & 15u) << (4 * k);
+        }
+        const unsigned top = (unsigned)(z >> (stretch - 1)) & 1u;
+        const unsigned up = (unsigned)__shfl_up((int)top, 1);
+        const unsigned carry0 = base == 0 ? 1u : ((sw[FRONT / 4 - 1] & 0xFFu) == 0u ? 1u : 0u);
+        m = (z << 1) | (lane ? up : carry0);
+        const long long left = (long long)nbytes - (long long)base - p0;       // positions of this lane inside the stream
+        const int nvalid = left <= 0 ? 0 : (left >= stretch ? stretch : (int)left);
+        m &= nvalid >= 64 ? ~0ull : ((1ull << nvalid) - 1ull);
+    }
+    const unsigned mine = (unsigned)__popcll(m);
+    unsigned incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned u = (unsigned)__shfl_up((int)incl, d);
+        if (lane >= d) incl += u;
+    }
+    const unsigned total = (unsigned)__shfl((int)incl, 63);
+    rec[lane] = u32x4{(unsigned)m, (unsigned)(m >> 32), incl - mine, 0u};
+    const bool overflow = total > (unsigned)cmax;
+    if (!overflow) {
+        unsigned at = incl - mine;
+        unsigned long long mm = m;
+        while (mm) {
+            const int i = __ffsll((long long)mm) - 1;
+            mm &= mm - 1;
+            cpos[at++] = (unsigned short)(p0 + i);
         }
     }
-    if (entry != INVALID && entry != AFTER) count = W.ent_cnt[(size_t)s * EMAX + entry];
-    W.entry[s] = entry;
-    W.count[s] = count;
+    __syncthreads();
+    // candidates in front of position p, and whether p is one itself
+    auto rank_of = [&](unsigned p, bool &is_cand) -> unsigned {
+        const unsigned L = (p * inv) >> 20;
+        const unsigned bit = p - L * (unsigned)stretch;
+        const u32x4 r = rec[L];
+        const unsigned long long mk = ((unsigned long long)r.y << 32) | r.x;
+        is_cand = ((mk >> bit) & 1ull) != 0;
+        return r.z + (unsigned)__popcll(mk & ((1ull << bit) - 1ull));
+    };
+    JPEGX_PHASE(1);
+
+    bool poisoned = overflow;
+    if (overflow && lane == 0) __hip_atomic_fetch_or(ghead + 2, 1u, JPEGX_RLX_AGENT);
+    const size_t win_end = nbytes - base + FRONT;                              // the stream's end, from the window's start
+    const unsigned end_bits = (unsigned)((win_end < (size_t)(win - 16) ? win_end : (size_t)(win - 16)) * 8u);
+    unsigned nent = 0;
+    bool konst = false;
+    int lv = 1;                                                                // levels in use: 2^(lv-1) >= the longest chain (or the tables' depth)
+    while ((1u << (lv - 1)) < total && lv < levels) ++lv;
+    // chain from candidate c: where it leaves the segment and after how many blocks (binary lifting, top level down)
+    auto chase = [&](unsigned c, unsigned &blocks) -> unsigned {
+        unsigned cur = c, cnt = 0;
+        for (int k = lv - 1; k >= 0; --k) {
+            const unsigned nxt = J[k * cmax + cur];
+            if (nxt < EXIT) { cur = nxt; cnt += 1u << k; }
+        }
+        blocks = cnt + 1u;
+        return J[cur];
+    };
+    unsigned my_exit_if_entry = INVALID, my_blocks_if_entry = 0;              // lane j: entry j's exit and blocks
+    unsigned marks[2][3] = {{0u, 0u, 0u}, {0u, 0u, 0u}};                       // lane l: the way marks of candidates l and 64 + l
+    if (!poisoned) {
+        // ---- 2. one parse per candidate
+        for (unsigned c0 = 0; c0 < total; c0 += 64) {
+            const unsigned c = c0 + lane;
+            const bool have = c < total;
+            const unsigned p = have ? cpos[c] : 0u;
+            unsigned mk[3];
+            const unsigned e = parse_tab(sw, tab, (FRONT + p) * 8u, end_bits, have, mk);
+            // candidates beyond the 128th go without way marks: one lane decodes such a block alone
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                if (c0 == 0) marks[0][k] = mk[k];
+                if (c0 == 64) marks[1][k] = mk[k];
+            }
+            unsigned code = INVALID;
+            if (e != NIL) {
+                const unsigned er = e - FRONT;
+                if (base + er == nbytes) code = END;
+                else if (er >= (unsigned)seg) code = EXIT | (er - (unsigned)seg);
+                else {
+                    bool is_cand;
+                    const unsigned i = rank_of(er, is_cand);
+                    code = is_cand ? i : INVALID;
+                }
+            }
+            if (have) J[c] = (unsigned short)code;
+        }
+        __syncthreads();
+        JPEGX_PHASE(2);
+        // J[k][c] = the candidate 2^k blocks behind c, or the terminal code the chain meets before that
+        for (int k = 1; k < lv; ++k) {
+            const unsigned short *prev = J + (k - 1) * cmax;
+            unsigned short *cur = J + k * cmax;
+            for (unsigned c = lane; c < total; c += 64) {
+                const unsigned a = prev[c];
+                cur[c] = a < EXIT ? prev[a] : (unsigned short)a;
+            }
+            __syncthreads();
+        }
+        // ---- 3. the entries; if they all agree on the exit, the segment behind can go on at once
+        bool dummy_b;
+        nent = total ? rank_of(REACH + 1, dummy_b) : 0u;
+        if ((unsigned)lane < nent) my_exit_if_entry = chase((unsigned)lane, my_blocks_if_entry);
+        if (nent >= 1 && nent <= 64) {
+            const unsigned x = my_exit_if_entry;
+            const unsigned long long valid = __ballot(x != INVALID);
+            if (valid) {
+                const unsigned x0 = (unsigned)__shfl((int)x, __ffsll((long long)valid) - 1);
+                konst = __ballot(x != INVALID && x != x0) == 0;
+                if (konst && lane == 0) __hip_atomic_store(gE + s, TAG | x0, JPEGX_RLX_AGENT);
+            }
+        }
+    }
+    JPEGX_PHASE(3);
+
+    // ---- 4. the entry (from the exit in front) and the number of blocks
+    unsigned entry = INVALID, myexit = INVALID, count = 0, err = 0;
+    if (!poisoned) {
+        if (s == 0) {
+            entry = total ? 0u : INVALID;                                      // position 0 is candidate 0 of segment 0
+        } else {
+            unsigned x = 0;
+            unsigned dbg_spins = 0;
+            for (unsigned spins = 0;;) {
+                x = __hip_atomic_load(gE + (s - 1), JPEGX_RLX_AGENT);
+                if (x != 0) break;
+                ++dbg_spins;
+                if (++spins > SPIN_LIMIT) { poisoned = true; break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            x &= 0xFFFFu;
+            (void)dbg_spins;
+#ifdef JPEGX_DECODE_STATS
+            if (lane == 0) trace[12] = dbg_spins;
+#endif
+            if (poisoned || x == POISON) poisoned = true;
+            else if (x == END || x == AFTER) entry = AFTER;
+            else if (is_exit(x)) {
+                const unsigned rel = x & 0x7FFFu;
+                bool is_cand = false;
+                const unsigned i = rel < (unsigned)seg ? rank_of(rel, is_cand) : 0u;
+                entry = is_cand ? i : INVALID;
+            }
+        }
+    }
+    JPEGX_PHASE(4);
+    if (!poisoned) {
+        if (entry == AFTER) myexit = AFTER;
+        else if (entry == INVALID) err |= 2u;
+        else {
+            if (entry < 64u && entry < nent) {                                 // chased already, by lane `entry`
+                myexit = (unsigned)__shfl((int)my_exit_if_entry, (int)entry);
+                count = (unsigned)__shfl((int)my_blocks_if_entry, (int)entry);
+            } else {
+                myexit = chase(entry, count);
+            }
+            if (myexit == INVALID) { err |= 2u; count = 0; }
+        }
+        if (err && lane == 0) __hip_atomic_fetch_or(ghead + 1, err, JPEGX_RLX_AGENT);
+        // block r of the segment is the candidate r steps from the entry: its byte position and its way marks (held by
+        // the lane that parsed it)
+        for (unsigned r0 = 0; r0 < count; r0 += 64) {
+            const unsigned r = r0 + lane;
+            unsigned cur = entry;
+            if (r < count)
+                for (int k = 0; k < lv; ++k)
+                    if ((r >> k) & 1u) cur = J[k * cmax + cur];
+            unsigned mk[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const unsigned a = (unsigned)__shfl((int)marks[0][k], (int)(cur & 63u)), b = (unsigned)__shfl((int)marks[1][k], (int)(cur & 63u));
+                mk[k] = cur < 64u ? a : (cur < 128u ? b : 0u);
+            }
+            if (r < count) W.prov[(size_t)s * cmax + r] = u32x4{(unsigned)base + cpos[cur], mk[0], mk[1], mk[2]};
+        }
+    } else if (lane == 0) {
+        __hip_atomic_fetch_or(ghead + 2, 2u, JPEGX_RLX_AGENT);
+    }
+    if (lane == 0) {
+        if (poisoned) __hip_atomic_store(gE + s, TAG | POISON, JPEGX_RLX_AGENT);
+        else if (!konst || myexit == INVALID) __hip_atomic_store(gE + s, TAG | myexit, JPEGX_RLX_AGENT);
+        W.C[s] = count;                 // where these blocks go in the plane's order is k_seg_scan's business: nobody waits for it here
+    }
+#ifdef JPEGX_DECODE_STATS
+    if (lane == 0) { trace[15] = total; trace[13] = konst ? 1 : 0; trace[14] = count; }
+#endif
+    JPEGX_PHASE(5);
 }
 
-// one workgroup: first block index of every segment (the proof that the entries chosen ARE the chain from 0 is spread
-// over the workgroups of k_seg_starts: every segment checks its own link to the next)
-__global__ __launch_bounds__(1024) void k_seg_scan(unsigned nseg, int cmax, void *ws, long long nblocks, size_t nbytes, int seg)
+// One workgroup: index of every segment's first block (exclusive scan of the counts), for every wave of the block
+// decoder the segment that holds its first block, and the check that the stream holds the plane's number of blocks.  Chunks of 16 K segments: 16 consecutive counts per thread, all loads in flight at once
+// (a dependent load per count made this kernel 11 us for 11 000 segments).
+__global__ __launch_bounds__(1024) void k_seg_scan(unsigned nseg, int cmax, void *state, void *ws, long long nblocks, int parity)
 {
     __shared__ unsigned carry[16];
-    __shared__ unsigned base_s, bad_s;
-    const Ws W = carve(ws, nseg, cmax, nblocks);
+    __shared__ unsigned base_s;
+    const Ws W = carve(state, ws, nseg, cmax, nblocks, parity);
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    if (t == 0) { base_s = 0; bad_s = 0; }
+    const unsigned nwaves = (unsigned)((nblocks + 63) / 64);
+    if (t == 0) base_s = 0;
     __syncthreads();
-    for (unsigned i0 = 0; i0 < nseg; i0 += 1024) {
-        const unsigned i = i0 + t;
-        unsigned v = 0;
-        bool bad = false;
-        if (i < nseg) {
-            v = W.count[i];
-            bad = W.entry[i] == INVALID;                       // the links between the entries are checked by k_seg_starts
+    for (unsigned c0 = 0; c0 < nseg; c0 += 16384u) {
+        const unsigned i0 = c0 + (unsigned)t * 16u;
+        unsigned c[16];
+        if (i0 + 16u <= nseg) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const u32x4 v = *reinterpret_cast<const u32x4 *>(W.C + i0 + 4 * k);
+                c[4 * k] = v.x; c[4 * k + 1] = v.y; c[4 * k + 2] = v.z; c[4 * k + 3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) c[k] = i0 + k < nseg ? W.C[i0 + k] : 0u;
         }
-        if (bad) atomicOr(&bad_s, 1u);
-        unsigned incl = v;
+        unsigned sum = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) sum += c[k];
+        unsigned incl = sum;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
-            const unsigned u = __shfl_up(incl, d);
+            const unsigned u = (unsigned)__shfl_up((int)incl, d);
             if (lane >= d) incl += u;
         }
         if (lane == 63) carry[wv] = incl;
         __syncthreads();
-        unsigned base = base_s;
-        for (int k = 0; k < wv; ++k) base += carry[k];
-        if (i < nseg) W.first[i] = base + incl - v;
+        unsigned run = base_s + incl - sum;
+        for (int k = 0; k < wv; ++k) run += carry[k];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const unsigned i = i0 + k;
+            if (i < nseg) {
+                W.F[i] = run;
+                for (unsigned m = (run + 63u) & ~63u; m < run + c[k]; m += 64)      // at most a few: a segment holds about 46 candidates
+                    if ((m >> 6) < nwaves) W.wave_seg[m >> 6] = i;
+            }
+            run += c[k];
+        }
         __syncthreads();
-        if (t == 1023) base_s = base + incl;
+        if (t == 1023) base_s = run;
         __syncthreads();
     }
     if (t == 0) {
-        W.head[3] = base_s;
+        const unsigned run = base_s;
+        W.F[nseg] = run;
+        W.head[3] = run;
         unsigned err = 0;
-        if (bad_s) err |= 2u;                                  // the chain breaks (a malformed block) or does not end at the last byte
-        if ((long long)base_s < nblocks) err |= 1u;            // fewer blocks than the plane has
-        if ((long long)base_s > nblocks) err |= 4u;            // more: bytes behind the plane's last block
-        if (err && !(W.head[2] & 7u)) atomicOr(&W.head[1], err);
+        if ((long long)run < nblocks) err |= 1u;           // fewer blocks than the plane has
+        if ((long long)run > nblocks) err |= 4u;           // more: bytes behind the plane's last block
+        if (err) atomicOr(&W.head[1], err);
     }
 }
 
-__global__ __launch_bounds__(THREADS) void k_seg_starts(int seg, int cmax, int levels, unsigned nseg, void *ws, long long nblocks)
+// FOUR lanes per block, 64 blocks per workgroup of four waves, from LDS.  Where a block starts: the workgroup's first
+// block lies in segment wave_seg[w]; the first-block indices of that segment and the 64 behind it go into LDS, a lane
+// finds its block's segment there (the last one that starts at or in front of the block) and reads what k_seg_starts
+// left: the byte position and up to three way marks.  Wave p takes every block from its p-th mark (wave 0: from the
+// start) to the next one, or to the block's end: a quarter of the dependent steps.  The blocks' bytes are one
+// contiguous span of the stream, [start of the first, start of the block behind the last); `span_cap` bytes of LDS
+// hold it (the host sizes that from the stream's average, with room to spare); a workgroup whose span is longer --
+// at most 64 x 185 bytes -- reads its blocks from global memory like the general scheme's kernel.
+__global__ __launch_bounds__(256) void k_dec_blocks_lds(const unsigned char *__restrict__ bytes, size_t nbytes, unsigned nseg, int cmax, void *state,
+                                                        const void *ws, int nblk, int span_cap, int16_t *__restrict__ out, int parity)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
-    const Ws W = carve(ws, nseg, cmax, nblocks);
-    if (W.head[1] != 0 || W.head[2] != 0) return;           // refused or handed to the general scheme: nothing to write
-    unsigned short *cpos = reinterpret_cast<unsigned short *>(sm);
-    unsigned short *J = cpos + cmax;
-    const unsigned s = blockIdx.x;
-    const int t = threadIdx.x;
-    const unsigned n = W.ncand[s], entry = W.entry[s], count = W.count[s], first = W.first[s];
-    if (t == 0 && entry != INVALID && entry != AFTER) {
-        // the link to the next segment: what the chain leaves this segment with is where the next one is entered, or the
-        // stream's last byte (then nothing may follow).  All links + entry 0 of segment 0 = the chain from position 0.
-        const unsigned x = W.ent_exit[(size_t)s * EMAX + entry];
-        bool bad;
-        if (x == END) bad = s + 1 < nseg && W.entry[s + 1] != AFTER;
-        else if (s + 1 < nseg) bad = !is_exit(x) || entry_of(W, s + 1, cmax, x & 0x7FFFu) != (int)W.entry[s + 1];
-        else bad = true;
-        if (bad) atomicOr(&W.head[1], 2u);
-    }
-    if (count == 0 || entry == INVALID || entry == AFTER) return;
-    for (unsigned c = t; c < n; c += THREADS) {
-        cpos[c] = W.pos[(size_t)s * cmax + c];
-        J[c] = W.j0[(size_t)s * cmax + c];
-    }
+    const Ws W = carve(state, const_cast<void *>(ws), nseg, cmax, nblk, parity);
+    // house-keeping for the NEXT call on this workspace, so that no call starts with a memset launch (4.5 us): the exit
+    // words go back to zero (k_seg_starts is done with them) and the other status block is cleared
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < nseg; i += gridDim.x * 256u) W.E[i] = 0u;
+    if (blockIdx.x == 0 && threadIdx.x < 16) W.next_head[threadIdx.x] = 0u;
+    if (W.head[1] != 0 || W.head[2] != 0) return;        // refused, or handed to the general scheme: the block starts are not there
+    const int t = threadIdx.x, lane = t & 63, part = t >> 6;
+    const int tile_idx = blockIdx.x, g0 = tile_idx * 64, g = g0 + lane;
+#ifdef JPEGX_DECODE_STATS
+    unsigned long long *trace3 = W.trace + 8 + (size_t)tile_idx * 16;
+    if (t == 0 && (unsigned)tile_idx < nseg) trace3[7] = wall_clock64();
+#define JPEGX_PHASE3(k) do { if (t == 0 && (unsigned)tile_idx < nseg) trace3[k] = wall_clock64(); } while (0)
+#else
+#define JPEGX_PHASE3(k) do { } while (0)
+#endif
+    unsigned char *tile = sm + span_cap;
+    unsigned char *dummy = tile + 64 * ROW + t * 4;
+    unsigned *Fs = reinterpret_cast<unsigned *>(tile + 64 * ROW + 1024);       // [65] first-block indices from segment s0 on, [66] [67]: the span
+    for (int i = t; i < 64 * ROW / 16; i += 256) *reinterpret_cast<u32x4 *>(tile + i * 16) = u32x4{0u, 0u, 0u, 0u};
+    const unsigned s0 = W.wave_seg[tile_idx];
+    if (t <= 64) Fs[t] = s0 + t <= nseg ? W.F[s0 + t] : 0xFFFFFFFFu;
     __syncthreads();
-    double_up(J, cmax, levels, (int)n);
-    for (unsigned r = t; r < count; r += THREADS) {
-        unsigned cur = entry;
-        for (int k = 0; k < levels; ++k)
-            if ((r >> k) & 1u) cur = J[(size_t)k * cmax + cur];
-        if ((long long)(first + r) < nblocks) W.start_pos[first + r] = (unsigned)((size_t)s * seg) + cpos[cur];
+    auto entry_of = [&](unsigned blk) -> u32x4 {          // what k_seg_starts left for block blk (>= the workgroup's first)
+        unsigned lo = 0, hi = 65;                           // the last of the 65 loaded segments that starts at or in front of blk
+        while (hi - lo > 1) {
+            const unsigned mid = (lo + hi) >> 1;
+            if (Fs[mid] <= blk) lo = mid; else hi = mid;
+        }
+        unsigned sgm = s0 + lo, first = Fs[lo];
+        if (lo == 64) {                                     // more than 64 segments for 64 blocks (empty ones in between): search on in global memory
+            unsigned a = s0 + 64, b = nseg;                 // F[a] <= blk < F[nseg] = blocks in the stream
+            while (b - a > 1) {
+                const unsigned mid = a + ((b - a) >> 1);
+                if (W.F[mid] <= blk) a = mid; else b = mid;
+            }
+            sgm = a; first = W.F[a];
+        }
+        return W.prov[(size_t)sgm * cmax + (blk - first)];
+    };
+    const bool have = g < nblk;
+    const u32x4 ent = entry_of(have ? (unsigned)g : (unsigned)g0);
+    const unsigned p = ent.x;
+    if (t == 0) Fs[66] = p;
+    if (t == 64) Fs[67] = g0 + 64 < nblk ? entry_of((unsigned)g0 + 64u).x : (unsigned)nbytes;   // the block behind the last: wave 1 has time for it
+    __syncthreads();
+    const unsigned p_lo = Fs[66], p_hi = Fs[67];
+    unsigned p_next = (unsigned)__shfl_down((int)p, 1);    // where the lane's block must end: the next block's start
+    if (lane == 63 || g + 1 >= nblk) p_next = g + 1 >= nblk ? (unsigned)nbytes : p_hi;
+    const unsigned w0 = p_lo & ~15u;                       // the window's first byte
+    JPEGX_PHASE3(8);
+    bool ok = true;
+    if (p_hi >= p_lo && p_hi - w0 + 40 <= (unsigned)span_cap && p >= p_lo && p <= p_hi) {
+        stage_pieces<3, 256>(bytes, nbytes, (long long)w0, (int)((p_hi - w0 + 24 + 15) / 16), sm, t);   // + the bit reader's look-ahead; 64 x 185 / 16 / 256 < 3
+        __syncthreads();
+        JPEGX_PHASE3(9);
+        const unsigned marks[3] = {ent.y, ent.z, ent.w};
+        const unsigned q0 = (p - w0) * 8u;
+        const unsigned from = part == 0 ? 0u : marks[part - 1];                 // bit offset << 8 | coefficients so far; 0: the block ends before
+        const unsigned to = part < 3 ? marks[part] : 0u;
+        const bool mine = have && (part == 0 || from != 0u);
+        const unsigned q_stop = to != 0u ? q0 + (to >> 8) : 0xFFFFFFFFu;
+        const unsigned q = parse_coefficients(reinterpret_cast<const unsigned *>(sm), q0 + (from >> 8), from & 0xFFu, q_stop, tile + lane * ROW, dummy, mine);
+        if (mine) {
+            if (to != 0u) ok = q == q_stop;                                    // the walk met the next way mark
+            else {
+                // ... or the block's end: an end marker, the zero padding, and the next block (the stream's end behind the last:
+                // bytes or whole blocks behind it make the reference fail in its reshape, run_length_encoding.py:77-79)
+                const unsigned *sw = reinterpret_cast<const unsigned *>(sm);
+                const unsigned wi = q >> 5;
+                const unsigned w = (unsigned)(((((unsigned long long)sw[wi] << 32) | sw[wi + 1]) << (q & 31u)) >> 32);
+                ok = (w >> 24) == 0u && w0 + ((q + 15u) >> 3) == p_next;
+            }
+        }
+    } else {
+        __syncthreads();
+        JPEGX_PHASE3(9);
+        if (have && part == 0) {
+            const unsigned e = parse_block<true>(reinterpret_cast<const unsigned *>(bytes), (unsigned long long)nbytes * 8u, p, tile, lane, ROW);
+            ok = e != NIL && e == p_next;
+        }
     }
+    if (__any(!ok) && lane == 0) atomicOr(&W.head[1], 2u);
+    __syncthreads();
+    JPEGX_PHASE3(10);
+    unsigned char *dst = reinterpret_cast<unsigned char *>(out) + (size_t)g0 * 128;
+    for (int i = t; i < 512; i += 256) {
+        const int row = i >> 3, ch = i & 7;
+        const u32x4 q = *reinterpret_cast<const u32x4 *>(tile + row * ROW + ch * 16);
+        if (g0 + row < nblk) *reinterpret_cast<u32x4 *>(dst + (size_t)row * 128 + ch * 16) = q;
+    }
+    JPEGX_PHASE3(11);
 }
 
 }  // namespace seg
@@ -607,41 +935,52 @@ int levels_for(long long nblocks)          // base-4 digits of the largest block
 SegPlan seg_plan(size_t nbytes, long long nblocks)
 {
     SegPlan p;
-    // about four thousand segments for a large stream, segments of 4 KiB at least: typical candidates per segment
-    // (one per block + a third again) stay far below the tables' capacity of a quarter of the bytes
-    int sg = 4096;
-    while (sg < 8192 && nbytes / (size_t)sg > 16384) sg *= 2;
-    p.seg = sg;
-    // table capacity: twice the candidates an average segment holds (one per block and about a third again from zero
-    // bytes inside amplitudes), as a power of two between 128 and a quarter of the segment's bytes -- the tables are
-    // what limits how many segments a CU works on at a time
-    const double per_seg = 1.4 * (double)sg * (double)(nblocks > 0 ? nblocks : 1) / (double)(nbytes ? nbytes : 1);
-    int cm = 128;
-    while (cm < sg / 4 && (double)cm < 2.0 * per_seg) cm *= 2;
-    p.cmax = cm;
-    p.levels = 1;
-    while ((1 << (p.levels - 1)) < p.cmax) ++p.levels;
-    p.nseg = (unsigned)((nbytes + sg - 1) / sg);
-    p.ok = nbytes > 0 && p.nseg <= 262144u && nblocks > 0;
-    seg::carve(nullptr, p.nseg ? p.nseg : 1, p.cmax, nblocks > 0 ? nblocks : 1, &p.ws_bytes);
+    // One wave per segment and one parse per candidate: the segment should hold about 46 candidates, so that a 65th
+    // (a second pass through the parse loop for a handful of lanes) stays rare.  A candidate is a block start or a
+    // zero byte inside a block's bits; measured on 4096 x 4096 bands, one byte in 81 (noise, 91 bytes per block) to one
+    // in 150 (smooth, 28 bytes per block) is such a zero -- far more than the 1/256 of random bytes, because a run of 0
+    // makes the header's high nibble zero.  Segments are multiples of 256 bytes (4 bytes per lane), 256 bytes to 4 KiB.
+    const double per_block = (double)(nbytes ? nbytes : 1) / (double)(nblocks > 0 ? nblocks : 1);
+    const double per_byte = 1.0 / per_block + 1.0 / 90.0;
+    int k = (int)(46.0 / per_byte / 256.0 + 0.5);
+    const char *force = getenv("JPEGX_DECODE_SEG");                          // A/B runs
+    if (force && *force) k = atoi(force) / 256;
+    k = k < 1 ? 1 : (k > 16 ? 16 : k);
+    p.seg = 256 * k;
+    p.cmax = 128;                    // candidates a segment's tables hold (a power of two): two and a half times the average
+    const char *fc = getenv("JPEGX_DECODE_CMAX");
+    if (fc && *fc) { p.cmax = 64; while (p.cmax < atoi(fc) && p.cmax < 2048) p.cmax *= 2; }
+    p.levels = seg::levels_of(p.cmax);
+    p.nseg = (unsigned)((nbytes + p.seg - 1) / p.seg);
+    // the block decoder's LDS span: 64 average blocks and half again (never more than 64 blocks can be: 64 x 185 bytes)
+    size_t span = (size_t)(per_block * 64.0 * 1.5) + 64;
+    span = (span + 15) & ~(size_t)15;
+    if (span < 1024) span = 1024;
+    if (span > 64 * 185 + 48) span = 64 * 185 + 48;
+    p.span_cap = (int)span;
+    p.ok = nbytes > 0 && (size_t)p.nseg * p.cmax * 16 <= ((size_t)1 << 32) && nblocks > 0;
+    seg::carve(nullptr, nullptr, p.nseg ? p.nseg : 1, p.cmax, nblocks > 0 ? nblocks : 1, 0, &p.ws_bytes, &p.state_bytes);
     return p;
 }
 
-void enqueue_segmented(const uint8_t *d_bytes, size_t nbytes, long long nblocks, const SegPlan &p, void *d_ws, int16_t *d_zz, hipStream_t st)
+void enqueue_segmented(const uint8_t *d_bytes, size_t nbytes, long long nblocks, const SegPlan &p, void *d_state, size_t state_cap, bool fresh, int parity,
+                       void *d_ws, int16_t *d_zz, hipStream_t st)
 {
-    (void)hipMemsetAsync(d_ws, 0, 16, st);
-    const size_t lds_parse = (size_t)((p.seg + 264) / 4) * 4 + (size_t)p.cmax * 2 * (1 + p.levels);
-    const size_t lds_starts = (size_t)p.cmax * 2 * (1 + p.levels);
-    hipLaunchKernelGGL(seg::k_seg_parse, dim3(p.nseg), dim3(seg::THREADS), lds_parse, st, d_bytes, nbytes, p.seg, p.cmax, p.levels, p.nseg, d_ws, nblocks);
-    hipLaunchKernelGGL(seg::k_seg_entries, dim3((p.nseg + seg::THREADS - 1) / seg::THREADS), dim3(seg::THREADS), 0, st, p.nseg, p.cmax, d_ws, nblocks);
-    hipLaunchKernelGGL(seg::k_seg_scan, dim3(1), dim3(1024), 0, st, p.nseg, p.cmax, d_ws, nblocks, nbytes, p.seg);
-    hipLaunchKernelGGL(seg::k_seg_starts, dim3(p.nseg), dim3(seg::THREADS), lds_starts, st, p.seg, p.cmax, p.levels, p.nseg, d_ws, nblocks);
-    const seg::Ws W = seg::carve(d_ws, p.nseg, p.cmax, nblocks);
-    hipLaunchKernelGGL(k_dec_blocks_guarded, dim3((unsigned)((nblocks + 63) / 64)), dim3(64), 0, st, reinterpret_cast<const unsigned *>(d_bytes), nbytes,
-                       W.start_pos, (int)nblocks, d_zz, W.head);
+    // the state (status blocks, exit words) is zero when a call starts: a fresh allocation is cleared once, whole; after
+    // that every call's block decoder clears what the call used
+    if (fresh) (void)hipMemsetAsync(d_state, 0, state_cap, st);
+#ifdef JPEGX_DECODE_STATS
+    (void)hipMemsetAsync(d_ws, 0, p.ws_bytes, st);
+#endif
+    const unsigned run8 = 8u << seg::RUN_LOG;                // the grid covers whole rounds of the XCDs' turns; the surplus returns at once
+    hipLaunchKernelGGL(seg::k_seg_starts, dim3((p.nseg + run8 - 1) / run8 * run8), dim3(64), seg::lds_bytes(p.seg, p.cmax), st, d_bytes, nbytes, p.seg, p.cmax,
+                       p.nseg, d_state, d_ws, nblocks, parity);
+    hipLaunchKernelGGL(seg::k_seg_scan, dim3(1), dim3(1024), 0, st, p.nseg, p.cmax, d_state, d_ws, nblocks, parity);
+    hipLaunchKernelGGL(seg::k_dec_blocks_lds, dim3((unsigned)((nblocks + 63) / 64)), dim3(256), seg::dec_lds_bytes(p.span_cap), st, d_bytes, nbytes,
+                       p.nseg, p.cmax, d_state, d_ws, (int)nblocks, p.span_cap, d_zz, parity);
 }
 
-size_t phase1_bytes(size_t nbytes) { return 16 + ((nbytes + CHUNK - 1) / CHUNK + 1) * 4; }
+size_t phase1_bytes(size_t nbytes) { return 64 + ((nbytes + CHUNK - 1) / CHUNK + 1) * 4; }   // the status words are read back as one 64-byte piece
 
 size_t phase2_bytes(size_t ncand, long long nblocks)
 {

@@ -78,6 +78,11 @@ constexpr int MAX_BANDS = JPEGX_MAX_IMAGE_BANDS;
 // the device-side working set of one band
 struct BandSlot {
     Span d_in, d_zz, d_ws, d_out, d_tmp;
+    Span d_seg, d_seg_state;      // the segmented entropy decoder's scratch, and its state: that stays clean from call to call
+    void *seg_clean = nullptr;    // the allocation that has been cleared
+    size_t seg_clean_cap = 0;
+    unsigned seg_calls = 0;
+    int seg_parity = -1;          // status block of the last decode (-1: the general scheme ran, status in d_ws)
 };
 
 struct DevicePool {
@@ -460,12 +465,18 @@ int decode_on_device(BandSlot &slot, size_t nbytes, long long nblocks, hipStream
     const char *force = getenv("JPEGX_DECODE_GENERAL");    // tests / A-B runs: the general scheme from the start
     if (force && *force && *force != '0') general = true;
     if (!general && plan.ok) {
-        if ((rc = slot.d_ws.ensure(plan.ws_bytes))) return rc;
-        jpegx_decode::enqueue_segmented(static_cast<const uint8_t *>(slot.d_in.p), nbytes, nblocks, plan, slot.d_ws.p,
-                                        static_cast<int16_t *>(slot.d_zz.p), st);
+        if ((rc = slot.d_seg.ensure(plan.ws_bytes)) || (rc = slot.d_seg_state.ensure(plan.state_bytes))) return rc;
+        bool fresh = slot.d_seg_state.p != slot.seg_clean || slot.d_seg_state.cap != slot.seg_clean_cap;
+        if (const char *ff = getenv("JPEGX_DECODE_FRESH")) fresh = fresh || (*ff && *ff != '0');      // tests: clear the state on every call
+        slot.seg_clean = slot.d_seg_state.p;
+        slot.seg_clean_cap = slot.d_seg_state.cap;
+        slot.seg_parity = (int)(slot.seg_calls++ & 1u);
+        jpegx_decode::enqueue_segmented(static_cast<const uint8_t *>(slot.d_in.p), nbytes, nblocks, plan, slot.d_seg_state.p, slot.d_seg_state.cap, fresh,
+                                        slot.seg_parity, slot.d_seg.p, static_cast<int16_t *>(slot.d_zz.p), st);
         HP_TRY(hipGetLastError());
         return JPEGX_OK;
     }
+    slot.seg_parity = -1;
     if ((rc = slot.d_ws.ensure(jpegx_decode::phase1_bytes(nbytes)))) return rc;
     jpegx_decode::enqueue_phase1(static_cast<const uint8_t *>(slot.d_in.p), nbytes, slot.d_ws.p, st);
     unsigned head[4] = {0, 0, 0, 0};
@@ -483,11 +494,19 @@ int decode_on_device(BandSlot &slot, size_t nbytes, long long nblocks, hipStream
 // after the stream has been synchronised: JPEGX_OK, an error, or DECODE_RETRY_GENERAL
 int decode_status(BandSlot &slot, bool general)
 {
-    unsigned head[4] = {0, 0, 0, 0};
-    HP_TRY(hipMemcpy(head, slot.d_ws.p, 16, hipMemcpyDeviceToHost));
-    const char *force = getenv("JPEGX_DECODE_GENERAL");
-    if (force && *force && *force != '0') general = true;
-    if (!general && head[2] != 0) return DECODE_RETRY_GENERAL;
+    unsigned head[16] = {0};
+    const bool seg = slot.seg_parity >= 0;
+    const unsigned char *src = seg ? static_cast<const unsigned char *>(slot.d_seg_state.p) + 64 * slot.seg_parity : static_cast<const unsigned char *>(slot.d_ws.p);
+    HP_TRY(hipMemcpy(head, src, 64, hipMemcpyDeviceToHost));
+    if (const char *dump = getenv("JPEGX_DECODE_STATS")) {     // a -DJPEGX_DECODE_STATS build leaves per-segment time stamps in its scratch
+        if (seg) {
+            std::vector<unsigned char> raw(slot.d_seg.cap);
+            HP_TRY(hipMemcpy(raw.data(), slot.d_seg.p, raw.size(), hipMemcpyDeviceToHost));
+            if (FILE *f = fopen(dump, "wb")) { fwrite(raw.data(), 1, raw.size(), f); fclose(f); }
+        }
+    }
+    (void)general;
+    if (seg && head[2] != 0) return DECODE_RETRY_GENERAL;
     if (head[1] != 0) return fail(JPEGX_E_INVALID, "entropy stream is not a sequence of well-formed blocks (device decoder)");
     return JPEGX_OK;
 }
