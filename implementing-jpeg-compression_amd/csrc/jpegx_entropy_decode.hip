@@ -363,7 +363,7 @@ __host__ __device__ inline size_t dec_lds_bytes(int span_cap) { return (size_t)s
 
 __host__ __device__ inline size_t lds_bytes(int seg, int cmax)
 {
-    return (size_t)(FRONT + seg + TAIL) + 64 * 16 + 256 + (size_t)cmax * 2 * (1 + levels_of(cmax));
+    return (size_t)(FRONT + seg + TAIL) + 64 * 16 + 256 + (size_t)cmax * (4 + levels_of(cmax));   // cpos, J0: 16 bit; the upper levels: bytes
 }
 
 constexpr int MARK_STEPS = 5;               // steps of three codes between two way marks
@@ -422,19 +422,18 @@ __device__ __forceinline__ unsigned parse_tab(const unsigned *sw, const unsigned
 }
 
 // The walk WITH the coefficients, into `row` (64 int16, zero beforehand), for the block decoder: from bit position q with n
-// coefficients behind it, up to the way mark q_stop (or to what ends the block).  No table here (the counter's advance is
-// arithmetic: run + 1 for an amplitude code, 15 for the chain code, 128 for what ends or breaks a block), two codes per
-// step, from the 64 bits at q (three dwords).  Stores go by address select (`dummy` when the code carries no amplitude
-// or the lane has stopped), not under a branch.
+// coefficients behind it, up to the way mark q_stop (or to the end marker).  k_seg_starts has walked the same codes and
+// found them a block, so nothing is checked here but what keeps a damaged workspace from doing harm: the coefficient
+// index is masked to the row and the steps are counted.  Two codes per step, from the 64 bits at q (three dwords);
+// stores go by address select (`dummy` when the code carries no amplitude or the lane has stopped), not under a branch.
 __device__ __forceinline__ unsigned parse_coefficients(const unsigned *sw, unsigned q, unsigned n, const unsigned q_stop, unsigned char *row,
                                                        unsigned char *dummy, bool live)
 {
-    auto advance = [](unsigned h) -> unsigned { return (h & 15u) >= 2u ? (h >> 4) + 1u : (h == 0xF0u ? 15u : 128u); };
     auto amplitude = [](unsigned w, unsigned size) -> int {
         const unsigned mag = __builtin_amdgcn_ubfe(w, 24u - size, size - 1u);
         return (w & 0x00800000u) ? (int)mag : -(int)mag;                     // sign bit '1' = positive
     };
-    while (__any(live)) {
+    for (int steps = 0; steps < 40 && __any(live); ++steps) {                // a block has at most 64 codes + the end marker
         const unsigned wi = q >> 5, sh = q & 31u;
         const unsigned d0 = sw[wi], d1 = sw[wi + 1], d2 = sw[wi + 2];
         const unsigned w1 = (unsigned)(((((unsigned long long)d0 << 32) | d1) << sh) >> 32);
@@ -442,16 +441,17 @@ __device__ __forceinline__ unsigned parse_coefficients(const unsigned *sw, unsig
         const unsigned h1 = w1 >> 24, s1 = h1 & 15u, q1 = q + 8u + s1;
         const unsigned w2 = (unsigned)(((((unsigned long long)w1 << 32) | x1) << (8u + s1)) >> 32);
         const unsigned h2 = w2 >> 24, s2 = h2 & 15u, q2 = q1 + 8u + s2;
-        const unsigned n1 = n + advance(h1), n2 = n1 + advance(h2);
-        const bool go1 = live && n1 <= 64u;
-        const bool go2 = go1 && q1 < q_stop && n2 <= 64u;
-        *reinterpret_cast<int16_t *>((go1 && s1 >= 2u) ? row + (n1 - 1u) * 2u : dummy) = (int16_t)amplitude(w1, s1);
-        *reinterpret_cast<int16_t *>((go2 && s2 >= 2u) ? row + (n2 - 1u) * 2u : dummy) = (int16_t)amplitude(w2, s2);
+        // an amplitude code advances the counter by run + 1, the chain code (size 0, run 15) by fifteen, the end marker stops
+        const unsigned n1 = n + (h1 >> 4) + (s1 >= 2u ? 1u : 0u), n2 = n1 + (h2 >> 4) + (s2 >= 2u ? 1u : 0u);
+        const bool go1 = live && h1 != 0u;
+        const bool go2 = go1 && q1 < q_stop && h2 != 0u;
+        *reinterpret_cast<int16_t *>((go1 && s1 >= 2u) ? row + ((n1 - 1u) & 63u) * 2u : dummy) = (int16_t)amplitude(w1, s1);
+        *reinterpret_cast<int16_t *>((go2 && s2 >= 2u) ? row + ((n2 - 1u) & 63u) * 2u : dummy) = (int16_t)amplitude(w2, s2);
         q = go2 ? q2 : (go1 ? q1 : q);
         n = go2 ? n2 : n1;
         live = go2 && q < q_stop;
     }
-    return q;       // the code the walk stopped in front of: the way mark it was told, or what ends the block
+    return q;       // the code the walk stopped in front of: the way mark it was told, or the end marker
 }
 
 // workgroup i (it runs on XCD i % 8) -> segment: the XCDs take turns in runs of 32 segments
@@ -540,7 +540,8 @@ __global__ __launch_bounds__(64) void k_seg_starts(const unsigned char *__restri
     u32x4 *rec = reinterpret_cast<u32x4 *>(sm + win);                          // per lane: candidate mask (64 bit), candidates in front
     unsigned char *tab = reinterpret_cast<unsigned char *>(rec + 64);
     unsigned short *cpos = reinterpret_cast<unsigned short *>(tab + 256);
-    unsigned short *J = cpos + cmax;                                           // [levels][cmax]: the candidate 2^k blocks on, or a terminal code
+    unsigned short *J = cpos + cmax;                                           // J0[c]: the candidate the block at c ends at, or a terminal code
+    unsigned char *Jk = reinterpret_cast<unsigned char *>(J + cmax) - cmax;    // Jk[k * cmax + c], k >= 1: the candidate 2^k blocks on, 0xFF: the chain ends before
 
     // ---- 1. the window
     const size_t base = (size_t)s * seg;
@@ -612,10 +613,12 @@ __global__ __launch_bounds__(64) void k_seg_starts(const unsigned char *__restri
     // chain from candidate c: where it leaves the segment and after how many blocks (binary lifting, top level down)
     auto chase = [&](unsigned c, unsigned &blocks) -> unsigned {
         unsigned cur = c, cnt = 0;
-        for (int k = lv - 1; k >= 0; --k) {
-            const unsigned nxt = J[k * cmax + cur];
-            if (nxt < EXIT) { cur = nxt; cnt += 1u << k; }
+        for (int k = lv - 1; k >= 1; --k) {
+            const unsigned nxt = Jk[k * cmax + cur];
+            if (nxt != 0xFFu) { cur = nxt; cnt += 1u << k; }
         }
+        const unsigned nxt0 = J[cur];
+        if (nxt0 < EXIT) { cur = nxt0; cnt += 1u; }
         blocks = cnt + 1u;
         return J[cur];
     };
@@ -652,11 +655,16 @@ __global__ __launch_bounds__(64) void k_seg_starts(const unsigned char *__restri
         JPEGX_PHASE(2);
         // J[k][c] = the candidate 2^k blocks behind c, or the terminal code the chain meets before that
         for (int k = 1; k < lv; ++k) {
-            const unsigned short *prev = J + (k - 1) * cmax;
-            unsigned short *cur = J + k * cmax;
             for (unsigned c = lane; c < total; c += 64) {
-                const unsigned a = prev[c];
-                cur[c] = a < EXIT ? prev[a] : (unsigned short)a;
+                unsigned two = 0xFFu;
+                if (k == 1) {
+                    const unsigned a = J[c];
+                    if (a < EXIT) { const unsigned b = J[a]; if (b < EXIT) two = b; }
+                } else {
+                    const unsigned a = Jk[(k - 1) * cmax + c];
+                    if (a != 0xFFu) two = Jk[(k - 1) * cmax + a];
+                }
+                Jk[k * cmax + c] = (unsigned char)two;
             }
             __syncthreads();
         }
@@ -725,9 +733,11 @@ __global__ __launch_bounds__(64) void k_seg_starts(const unsigned char *__restri
         for (unsigned r0 = 0; r0 < count; r0 += 64) {
             const unsigned r = r0 + lane;
             unsigned cur = entry;
-            if (r < count)
-                for (int k = 0; k < lv; ++k)
-                    if ((r >> k) & 1u) cur = J[k * cmax + cur];
+            if (r < count) {
+                if (r & 1u) cur = J[cur];
+                for (int k = 1; k < lv; ++k)
+                    if ((r >> k) & 1u) cur = Jk[k * cmax + cur];
+            }
             unsigned mk[3];
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
@@ -949,7 +959,7 @@ SegPlan seg_plan(size_t nbytes, long long nblocks)
     p.seg = 256 * k;
     p.cmax = 128;                    // candidates a segment's tables hold (a power of two): two and a half times the average
     const char *fc = getenv("JPEGX_DECODE_CMAX");
-    if (fc && *fc) { p.cmax = 64; while (p.cmax < atoi(fc) && p.cmax < 2048) p.cmax *= 2; }
+    if (fc && *fc) { p.cmax = 64; while (p.cmax < atoi(fc) && p.cmax < 128) p.cmax *= 2; }       // the upper table levels hold bytes: below 255
     p.levels = seg::levels_of(p.cmax);
     p.nseg = (unsigned)((nbytes + p.seg - 1) / p.seg);
     // the block decoder's LDS span: 64 average blocks and half again (never more than 64 blocks can be: 64 x 185 bytes)
