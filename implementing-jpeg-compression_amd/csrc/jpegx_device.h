@@ -306,6 +306,67 @@ __device__ __forceinline__ void census(unsigned long long *counters, unsigned lo
     }
 }
 
+// Bytes the entropy stage will write for a block (RunLengthEncoding + RleBytestream, pipeline/run_length_encoding.py:47-64,
+// pipeline/rle_byte_stream.py:48-59, util.py:134-156), from the block's 32 packed words (coefficients 2k, 2k + 1 of the
+// zigzag order in word k) while they are still in registers: 8 bits of end marker + per non-zero 4 + 4 + 1 + bit_length
+// bits + 8 per chain code of fifteen zeros, padded to bytes.  bad: an amplitude beyond 15 bits (util.py:140-149).
+// Two coefficients per instruction where the ISA allows: |.| by v_pk_sub / v_pk_max, "non-zero" by v_pk_min_u16 with
+// 1, the 64-bit non-zero mask by doubling an accumulator (word k's flags land in bits k and 16 + k: even and odd
+// coefficients apart, interleaved afterwards), bit lengths through v_ffbh_u32 (which says -1 for zero: the sum is
+// corrected by the number of zeros).
+__device__ __forceinline__ unsigned rle_block_bytes(const unsigned (&pk)[32], bool &bad)
+{
+    typedef short s16x2 __attribute__((ext_vector_type(2)));
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    int sumf = 0;
+    unsigned acc[2] = {0u, 0u}, any = 0u;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int k = 15; k >= 0; --k) {
+            const s16x2 x = __builtin_bit_cast(s16x2, pk[16 * h + k]);
+            const s16x2 neg = s16x2{0, 0} - x;
+            const s16x2 ab = __builtin_elementwise_max(x, neg);
+            const unsigned a = __builtin_bit_cast(unsigned, ab);
+            any |= a;
+            sumf += (int)__builtin_clz(((a & 0xFFFFu) << 1) | 1u) + (int)__builtin_clz(((a >> 16) << 1) | 1u);   // 31 - bit_length each
+            const u16x2 one = __builtin_elementwise_min(__builtin_bit_cast(u16x2, a), u16x2{1, 1});
+            acc[h] = acc[h] + acc[h] + __builtin_bit_cast(unsigned, one);
+        }
+    }
+    bad = (any & 0xC000C000u) != 0u;                                         // |a| > 16383 somewhere
+    const unsigned nnz = (unsigned)__popc(acc[0]) + (unsigned)__popc(acc[1]);
+    const unsigned sum_bl = 64u * 31u - (unsigned)sumf;                        // sum of the bit lengths (zero: length 0)
+    // the non-zero mask in coefficient order
+    unsigned m[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        unsigned e = acc[h] & 0xFFFFu, o = acc[h] >> 16;
+        e = (e | (e << 8)) & 0x00FF00FFu; o = (o | (o << 8)) & 0x00FF00FFu;
+        e = (e | (e << 4)) & 0x0F0F0F0Fu; o = (o | (o << 4)) & 0x0F0F0F0Fu;
+        e = (e | (e << 2)) & 0x33333333u; o = (o | (o << 2)) & 0x33333333u;
+        e = (e | (e << 1)) & 0x55555555u; o = (o | (o << 1)) & 0x55555555u;
+        m[h] = e | (o << 1);
+    }
+    const unsigned long long M = ((unsigned long long)m[1] << 32) | m[0];
+    // chain codes: one per fifteen zeros in front of a non-zero (see chain_count in jpegx_entropy.hip); rare enough to be
+    // decided by the wave
+    unsigned chains = 0;
+    {
+        const unsigned long long z = ~M;
+        const unsigned long long r2 = z & (z << 1), r4 = r2 & (r2 << 2), r8 = r4 & (r4 << 4);
+        const unsigned long long r15 = r8 & (r8 << 7);
+        if (__any(((r15 << 1) & M) != 0ull)) {
+            const unsigned long long r30 = r15 & (r15 << 15);
+            const unsigned long long r45 = r30 & (r15 << 30);
+            const unsigned long long r60 = r30 & (r30 << 30);
+            chains = (unsigned)(__popcll((r15 << 1) & M) + __popcll((r30 << 1) & M) + __popcll((r45 << 1) & M) + __popcll((r60 << 1) & M));
+        }
+    }
+    const unsigned bits = 8u + sum_bl + 9u * nnz + 8u * chains;
+    return (bits + 7u) >> 3;
+}
+
 // XCD-private block order.  Workgroups are dealt round-robin over the 8 XCDs, so with the natural numbering
 // every XCD touches -- and translates for itself -- every 2 MiB page of both streams.  Here workgroup i of
 // XCD (i % 8) takes strip ((j >> logr) * 8 + i % 8) << logr | (j & (2^logr - 1)), j = i / 8: the XCDs take

@@ -168,6 +168,10 @@ __global__ __launch_bounds__(1024) void k_scan_level1(int nwaves, void *ws, int 
         if (i0 + 1 < nwaves) v.y = W.wave_bytes[i0 + 1];
         if (i0 + 2 < nwaves) v.z = W.wave_bytes[i0 + 2];
     }
+    // bit 31 of a wave's total: an amplitude beyond 15 bits there (set by the forward kernels that size their own blocks)
+    const bool bad = ((v.x | v.y | v.z | v.w) & 0x80000000u) != 0u;
+    v.x &= 0x7FFFFFFFu; v.y &= 0x7FFFFFFFu; v.z &= 0x7FFFFFFFu; v.w &= 0x7FFFFFFFu;
+    if (__any(bad) && lane == 0) atomicOr(W.error, 1u);
     const unsigned s = v.x + v.y + v.z + v.w;
     unsigned incl = s;
 #pragma unroll
@@ -183,6 +187,50 @@ __global__ __launch_bounds__(1024) void k_scan_level1(int nwaves, void *ws, int 
     const unsigned e = base + incl - s;                   // exclusive prefix of this thread's 4 waves
     *reinterpret_cast<u32x4 *>(W.wave_off + i0) = u32x4{e, e + v.x, e + v.x + v.y, e + v.x + v.y + v.z};
     if (t == 1023) W.chunk_off[blockIdx.x] = (unsigned long long)(base + incl);   // chunk total, scanned next
+}
+
+// The two levels in one launch when the waves fit one chunk (a 4096 x 4096 band: exactly), for the path whose sizes come
+// from the forward kernel: offsets, total and the error flag are WRITTEN here (bit 31 of the waves' totals), so the
+// workspace's head needs no clearing beforehand.
+__global__ __launch_bounds__(1024) void k_scan_one_chunk(int nwaves, void *ws, int nblk)
+{
+    __shared__ unsigned carry[16];
+    __shared__ unsigned bad_s[16];
+    const Workspace W = carve(ws, nblk);
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int i0 = t * 4;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (i0 + 3 < nwaves) {
+        v = *reinterpret_cast<const u32x4 *>(W.wave_bytes + i0);
+    } else {
+        if (i0 + 0 < nwaves) v.x = W.wave_bytes[i0 + 0];
+        if (i0 + 1 < nwaves) v.y = W.wave_bytes[i0 + 1];
+        if (i0 + 2 < nwaves) v.z = W.wave_bytes[i0 + 2];
+    }
+    const bool bad = ((v.x | v.y | v.z | v.w) & 0x80000000u) != 0u;
+    v.x &= 0x7FFFFFFFu; v.y &= 0x7FFFFFFFu; v.z &= 0x7FFFFFFFu; v.w &= 0x7FFFFFFFu;
+    const unsigned s = v.x + v.y + v.z + v.w;
+    unsigned incl = s;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned u = __shfl_up(incl, d);
+        if (lane >= d) incl += u;
+    }
+    if (lane == 63) carry[wv] = incl;
+    if (lane == 0) bad_s[wv] = __any(bad) ? 1u : 0u;
+    __syncthreads();
+    unsigned base = 0, anybad = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { base += (k < wv) ? carry[k] : 0u; anybad |= bad_s[k]; }
+    const unsigned e = base + incl - s;
+    *reinterpret_cast<u32x4 *>(W.wave_off + i0) = u32x4{e, e + v.x, e + v.x + v.y, e + v.x + v.y + v.z};
+    if (t == 1023) {
+        const unsigned long long total = (unsigned long long)(base + incl);
+        W.chunk_off[0] = 0;
+        W.chunk_off[1] = total;
+        *W.total = total;
+        *W.error = anybad;
+    }
 }
 
 __global__ __launch_bounds__(64) void k_scan_level2(int nchunks, void *ws, int nblk)
@@ -324,6 +372,31 @@ int jpegx_entropy_sizes(const int16_t *d_zz, long long nblocks, void *d_workspac
     hipLaunchKernelGGL(k_rle_sizes, dim3(nw), dim3(64), 0, st, d_zz, nblk, d_workspace);
     hipLaunchKernelGGL(k_scan_level1, dim3(nchunks), dim3(1024), 0, st, nw, d_workspace, nblk);
     hipLaunchKernelGGL(k_scan_level2, dim3(1), dim3(64), 0, st, nchunks, d_workspace, nblk);
+    HIP_TRY(hipGetLastError());
+    return JPEGX_OK;
+}
+
+// internal: where the forward kernels that size their own blocks put the sizes, and the scans behind them
+void jpegx_internal_entropy_views(void *d_workspace, long long nblocks, unsigned **block_bytes, unsigned **wave_bytes)
+{
+    const Workspace W = carve(d_workspace, nblocks);
+    *block_bytes = W.block_bytes;
+    *wave_bytes = W.wave_bytes;
+}
+
+int jpegx_internal_entropy_scan(long long nblocks, void *d_workspace, jpegx_stream_t stream)
+{
+    if (!d_workspace || nblocks <= 0 || nblocks > 0x7FFFFFC0LL) return fail(JPEGX_E_INVALID, "bad scan arguments");
+    const int nblk = (int)nblocks, nw = (nblk + 63) / 64;
+    hipStream_t st = (hipStream_t)stream;
+    const int nchunks = (nw + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    if (nchunks == 1) {
+        hipLaunchKernelGGL(k_scan_one_chunk, dim3(1), dim3(1024), 0, st, nw, d_workspace, nblk);
+    } else {
+        HIP_TRY(hipMemsetAsync(d_workspace, 0, 16, st));
+        hipLaunchKernelGGL(k_scan_level1, dim3(nchunks), dim3(1024), 0, st, nw, d_workspace, nblk);
+        hipLaunchKernelGGL(k_scan_level2, dim3(1), dim3(64), 0, st, nchunks, d_workspace, nblk);
+    }
     HIP_TRY(hipGetLastError());
     return JPEGX_OK;
 }

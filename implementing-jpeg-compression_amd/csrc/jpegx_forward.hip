@@ -983,10 +983,14 @@ __global__ __launch_bounds__(64) void k_forward_fused_f64in(const double *__rest
 #else
 #define JPEGX_U8_OCC __attribute__((amdgpu_waves_per_eu(BS == 1 ? 5 : 2)))
 #endif
-template <bool DC_EXACT, int BS, bool NT>
+// SIZES: the entropy stage's byte count of every block, from the registers (rle_block_bytes): block_bytes[block] and
+// the wave's total (bit 31: an amplitude beyond 15 bits in the wave) -> wave_bytes[wave]; k_rle_sizes then has nothing
+// left to read the stream for.
+template <bool DC_EXACT, int BS, bool NT, bool SIZES = false>
 __global__ __launch_bounds__(64) JPEGX_U8_OCC void k_forward_fused_u8(const unsigned char *__restrict__ in, size_t pitch, int wb,
                                                          int nblk, QuantParams prm, int16_t *__restrict__ out,
-                                                         unsigned long long *counters)
+                                                         unsigned long long *counters, unsigned *__restrict__ block_bytes = nullptr,
+                                                         unsigned *__restrict__ wave_bytes = nullptr)
 {
     constexpr int ROWS = 8 * BS;                       // input rows of the wave's blocks
     constexpr int ROW_BYTES = 64 * 8 * BS;             // bytes of one input row in LDS (64 blocks)
@@ -1176,6 +1180,16 @@ __global__ __launch_bounds__(64) JPEGX_U8_OCC void k_forward_fused_u8(const unsi
         }
     }
 
+    if (SIZES) {
+        bool bad;
+        unsigned bytes = rle_block_bytes(pk, bad);
+        if (!valid) { bytes = 0; bad = false; }
+        if (valid) block_bytes[g0 + lane] = bytes;
+        unsigned sum = bytes;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d);
+        if (lane == 0) wave_bytes[blockIdx.x] = sum | (__any(bad) ? 0x80000000u : 0u);
+    }
     if (prm.tune & 4) {
         // A/B (JPEGX_F_TUNE_DIRECT_STORE): every lane stores its own 128 bytes, eight 16-byte pieces at a 128-byte
         // lane stride, default cache policy so that L2 merges the pieces of a line -- no LDS tile, no barriers
@@ -1513,8 +1527,8 @@ int jpegx_forward_fused(const float *d_in, int H, int W, ptrdiff_t pitch, int mo
     return jpegx_forward_fused_pooled(d_in, H, W, pitch, 1, mode, param, flags, d_out, stream);
 }
 
-int jpegx_forward_fused_u8(const uint8_t *d_in, int H, int W, ptrdiff_t pitch, int bs, int mode, double param,
-                           unsigned flags, int16_t *d_out, jpegx_stream_t stream)
+static int forward_u8_common(const uint8_t *d_in, int H, int W, ptrdiff_t pitch, int bs, int mode, double param,
+                             unsigned flags, int16_t *d_out, unsigned *block_bytes, unsigned *wave_bytes, jpegx_stream_t stream)
 {
     if (bs != 1 && bs != 2 && bs != 4) return fail(JPEGX_E_UNSUPPORTED, "uint8 forward supports block_size 1, 2 and 4");
     int rc = check_plane(d_in, d_out, H, W, pitch / bs, 1);
@@ -1534,17 +1548,35 @@ int jpegx_forward_fused_u8(const uint8_t *d_in, int H, int W, ptrdiff_t pitch, i
     hipStream_t st = (hipStream_t)stream;
     const bool dc_exact = is_pow2_float(qp.rq32[0]) && (qp.mode != JPEGX_Q_DIVIDE || (double)qp.rq32[0] * qp.param == 1.0);
     const bool nt = !(flags & JPEGX_F_TUNE_NO_NT);
+    const bool sizes = block_bytes != nullptr;
     QuantParams qa = qp;
     scale_for_aan(&qa);
+#define JPEGX_LU8K(DC, BSV, NTV, SZ) \
+    hipLaunchKernelGGL((k_forward_fused_u8<DC, BSV, NTV, SZ>), grid, block, 0, st, d_in, (size_t)pitch, wb, nblk, qa, d_out, g_counters, block_bytes, wave_bytes)
 #define JPEGX_LU8(DC, BSV) \
-    do { if (nt) hipLaunchKernelGGL((k_forward_fused_u8<DC, BSV, true>), grid, block, 0, st, d_in, (size_t)pitch, wb, nblk, qa, d_out, g_counters); \
-         else hipLaunchKernelGGL((k_forward_fused_u8<DC, BSV, false>), grid, block, 0, st, d_in, (size_t)pitch, wb, nblk, qa, d_out, g_counters); } while (0)
+    do { if (sizes) { if (nt) JPEGX_LU8K(DC, BSV, true, true); else JPEGX_LU8K(DC, BSV, false, true); } \
+         else { if (nt) JPEGX_LU8K(DC, BSV, true, false); else JPEGX_LU8K(DC, BSV, false, false); } } while (0)
     if (bs == 1) { if (dc_exact) JPEGX_LU8(true, 1); else JPEGX_LU8(false, 1); }
     else if (bs == 2) { if (dc_exact) JPEGX_LU8(true, 2); else JPEGX_LU8(false, 2); }
     else { if (dc_exact) JPEGX_LU8(true, 4); else JPEGX_LU8(false, 4); }
 #undef JPEGX_LU8
+#undef JPEGX_LU8K
     HIP_TRY(hipGetLastError());
     return JPEGX_OK;
+}
+
+int jpegx_forward_fused_u8(const uint8_t *d_in, int H, int W, ptrdiff_t pitch, int bs, int mode, double param,
+                           unsigned flags, int16_t *d_out, jpegx_stream_t stream)
+{
+    return forward_u8_common(d_in, H, W, pitch, bs, mode, param, flags, d_out, nullptr, nullptr, stream);
+}
+
+// internal (jpegx_internal.h): the same with the entropy stage's block sizes written into its workspace on the way
+int jpegx_internal_forward_u8_sized(const uint8_t *d_in, int H, int W, ptrdiff_t pitch, int bs, int mode, double param, unsigned flags,
+                                    int16_t *d_out, unsigned *block_bytes, unsigned *wave_bytes, jpegx_stream_t stream)
+{
+    if (!block_bytes || !wave_bytes) return fail(JPEGX_E_INVALID, "null workspace views");
+    return forward_u8_common(d_in, H, W, pitch, bs, mode, param, flags, d_out, block_bytes, wave_bytes, stream);
 }
 int jpegx_host_forward_fused_f64(const double *h_in, int H, int W, int mode, double param, unsigned flags, int16_t *h_out)
 {

@@ -25,6 +25,11 @@
 #include "jpegx_entropy_decode.h"
 
 extern "C" void jpegx_internal_set_error(const char *msg);
+// the uint8 forward kernels sizing their own blocks for the entropy stage (jpegx_forward.hip, jpegx_entropy.hip)
+extern "C" int jpegx_internal_forward_u8_sized(const uint8_t *d_in, int H, int W, ptrdiff_t pitch, int bs, int mode, double param, unsigned flags,
+                                               int16_t *d_out, unsigned *block_bytes, unsigned *wave_bytes, jpegx_stream_t stream);
+extern "C" void jpegx_internal_entropy_views(void *d_workspace, long long nblocks, unsigned **block_bytes, unsigned **wave_bytes);
+extern "C" int jpegx_internal_entropy_scan(long long nblocks, void *d_workspace, jpegx_stream_t stream);
 
 namespace {
 
@@ -260,8 +265,14 @@ int enqueue_front(DevicePool *pool, BandSlot &slot, uint8_t *stage, const void *
         : hipMemcpy2DAsync(slot.d_in.p, WW, src8, (size_t)src_pitch, WW, HH, hipMemcpyHostToDevice, st);
     if (e != hipSuccess) return fail(JPEGX_E_HIP, "host to device copy failed");
     if (fused_pool) {
-        rc = jpegx_forward_fused_u8(static_cast<const uint8_t *>(slot.d_in.p), H, W, WW, bs, mode, param, 0,
-                                    static_cast<int16_t *>(slot.d_zz.p), st);
+        // the forward kernel sizes its blocks from the registers (RunLengthEncoding's bit counts): no second pass over the
+        // stream, and the scan that follows writes the workspace's head itself -- two launches, no memset
+        unsigned *block_bytes = nullptr, *wave_bytes = nullptr;
+        jpegx_internal_entropy_views(slot.d_ws.p, nblocks, &block_bytes, &wave_bytes);
+        rc = jpegx_internal_forward_u8_sized(static_cast<const uint8_t *>(slot.d_in.p), H, W, WW, bs, mode, param, 0,
+                                             static_cast<int16_t *>(slot.d_zz.p), block_bytes, wave_bytes, st);
+        if (rc) return rc;
+        return jpegx_internal_entropy_scan(nblocks, slot.d_ws.p, st);
     } else {
         // any other block_size: SubSampling on the device in float64 (exact sum, one division), then the
         // all-float64 fused forward -- k/9, k/25 ... are not fp32 numbers
