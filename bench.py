@@ -28,6 +28,7 @@ configs   (N = 1) = BASELINE.json configs[2] (8192^2 YCbCr 4:2:0) and configs[3]
 cpu_baseline (N = 1) = the faithful Python/NumPy per-block loop restatement of the reference
             (oracle/ref_loop.py, 1 core) on three planes; the C oracle's rate is given too.
 """
+import ctypes
 import argparse
 import hashlib
 import json
@@ -279,11 +280,27 @@ def config_u8(jpegx, kind, iters, verify, planes=16):
 
     def inv():
         jpegx.check(jpegx.lib().jpegx_inverse_fused_u8_inflated(zz.ptr, H, n, jpegx.Q_QTABLE, 0.0, 0, 1, rec.ptr, n, None), "inverse_u8")
+
+    # what compress_band launches since round 3: the same kernel also counting the entropy stage's bits per block (the
+    # second pass over the stream, k_rle_sizes, is gone); an internal entry of the library, not part of include/jpegx.h
+    L = jpegx.lib()
+    ws = jpegx.DeviceBuffer(int(L.jpegx_entropy_workspace_bytes(blocks)))
+    bb, wb_ = ctypes.c_void_p(), ctypes.c_void_p()
+    L.jpegx_internal_entropy_views.argtypes = [ctypes.c_void_p, ctypes.c_longlong, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p)]
+    L.jpegx_internal_entropy_views.restype = None
+    L.jpegx_internal_entropy_views(ws.ptr, blocks, ctypes.byref(bb), ctypes.byref(wb_))
+    L.jpegx_internal_forward_u8_sized.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_ssize_t, ctypes.c_int, ctypes.c_int, ctypes.c_double,
+                                                  ctypes.c_uint, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    L.jpegx_internal_forward_u8_sized.restype = ctypes.c_int
+
+    def fwd_sized():
+        jpegx.check(L.jpegx_internal_forward_u8_sized(u8.ptr, H, n, n, 1, jpegx.Q_QTABLE, 0.0, 0, zz.ptr, bb, wb_, None), "forward_u8_sized")
     fwd()
     ms_f = _timed_launches(jpegx, fwd, iters)
+    ms_s = _timed_launches(jpegx, fwd_sized, iters)
     ms_i = _timed_launches(jpegx, inv, iters)
     res = {}
-    for name, ms in (("forward_u8_bs1", ms_f), ("inverse_u8", ms_i)):
+    for name, ms in (("forward_u8_bs1", ms_f), ("forward_u8_bs1_with_entropy_sizes", ms_s), ("inverse_u8", ms_i)):
         res[name] = {"ms": round(ms, 4), "blocks": blocks, "algorithmic_bytes": blocks * 192, "Mblocks_per_s": round(blocks / ms / 1e3, 1),
                      "GBps": round(blocks * 192 / ms / 1e6, 1), "frac": round(blocks * 192 / ms / 1e6 / HBM_PEAK_GBPS, 4)}
     if verify:
@@ -294,7 +311,7 @@ def config_u8(jpegx, kind, iters, verify, planes=16):
         back = rec.download((rows, n), np.uint8)
         res["verified_vs_oracle"] = bool(np.array_equal(got, want) and
                                          np.array_equal(back, np.clip(oracle.inverse_i16(want, "qtable"), 0, 255).astype(np.uint8)))
-    for b in (f32, u8, zz, rec):
+    for b in (f32, u8, zz, rec, ws):
         b.free()
     return res
 

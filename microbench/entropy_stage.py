@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The entropy stage on the device, both ways, for the record (profiles/rNN_entropy_stage.*): encode (k_rle_sizes + scans +
-k_rle_emit on a device-resident stream, HIP events) and decode (candidate compaction, parse, pointer doubling, starts,
-block decode; through jpegx_host_entropy_decode_gpu, so the wall time includes the copies -- the kernels' own times come
+k_rle_emit on a device-resident stream, HIP events) and decode (segment-local block starts, scan, block decode from LDS;
+through jpegx_host_entropy_decode_gpu, so the wall time includes the copies -- the kernels' own times come
 from `rocprofv3 --kernel-trace --stats -- python3 microbench/entropy_stage.py`).  4096 x 4096 planes, JPEG table.
 Algorithmic bytes: encode reads the 128-byte block twice (sizes, emit) and writes the code bytes; decode reads the code
 bytes and writes 128 bytes per block."""
@@ -67,7 +67,7 @@ def main():
             jpegx.entropy_decode_gpu(blob, nblk1)
             ts.append((time.perf_counter() - t0) * 1e3)
         out[kind]["decode_host_entry"] = {"blocks": nblk1, "coded_bytes": len(blob), "wall_ms_median": round(sorted(ts)[len(ts) // 2], 3),
-                                          "note": "H2D of the code bytes + 7 kernels (+ log2(blocks) pointer-doubling launches) + D2H of 32 MiB"}
+                                          "note": "H2D of the code bytes + 3 kernels (k_seg_starts, k_seg_scan, k_dec_blocks_lds) + D2H of 32 MiB"}
         for b in (src, zz, ws, coded, one):
             b.free()
     print(json.dumps(out))
