@@ -15,6 +15,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#include <sys/mman.h>
 
 #include <atomic>
 #include <mutex>
@@ -205,14 +206,31 @@ bool narrow_rows(const T *src, ptrdiff_t src_pitch, int H, int W, uint8_t *dst, 
 void prefault(uint8_t *p, size_t n)
 {
     if (n < (4u << 20)) return;
-    const unsigned hw = std::thread::hardware_concurrency();
-    const int nthreads = hw >= 8 ? 8 : (hw ? (int)hw : 1);
-    auto work = [&](size_t a, size_t b) {
-        for (size_t o = a; o < b; o += 4096) reinterpret_cast<volatile uint8_t *>(p)[o] = 0;
+    // What a fresh 128 MiB result array costs is the operating system's (NumPy asks for transparent huge pages: 64 faults
+    // of 2 MiB, ~5 ms on the GPU box for np.empty + one write per page) and none of the ways to pay it early was
+    // measured faster than letting the eight threads that fill the array fault it in (profiles/r03_prefault_ab.txt):
+    // 1 / 2 / 4 / 8 touching threads 16 / 12 / 11.5 / 11 ms per decompress_band call, MADV_POPULATE_WRITE 15 ms,
+    // nothing at all 11 ms -- against 2-3 ms when the allocator hands back pages that are already mapped.
+    static const int mode = [] { const char *e = getenv("JPEGX_PREFAULT"); return e && *e ? atoi(e) : 8; }();   // A/B: threads; -1 populate, -2 huge pages + populate; 0 off
+    if (mode == 0) return;
+    const uintptr_t lo = (reinterpret_cast<uintptr_t>(p) + 4095) & ~(uintptr_t)4095, hi = (reinterpret_cast<uintptr_t>(p) + n) & ~(uintptr_t)4095;
+    if (hi <= lo) return;
+    if (mode < 0) {
+#ifndef MADV_POPULATE_WRITE
+#define MADV_POPULATE_WRITE 23      /* Linux 5.14 */
+#endif
+        const uintptr_t hlo = (lo + (2u << 20) - 1) & ~(uintptr_t)((2u << 20) - 1), hhi = hi & ~(uintptr_t)((2u << 20) - 1);
+        if (mode == -2 && hhi > hlo) (void)madvise(reinterpret_cast<void *>(hlo), hhi - hlo, MADV_HUGEPAGE);
+        if (madvise(reinterpret_cast<void *>(lo), hi - lo, MADV_POPULATE_WRITE) == 0) return;
+    }
+    const int nthreads = mode > 0 ? mode : 1;
+    auto work = [&](uintptr_t a, uintptr_t b) {
+        for (uintptr_t o = a; o < b; o += 4096) { volatile uint8_t *q = reinterpret_cast<volatile uint8_t *>(o); *q = 0; }
     };
     std::vector<std::thread> th;
-    for (int t = 1; t < nthreads; ++t) th.emplace_back(work, n * t / nthreads, n * (t + 1) / nthreads);
-    work(0, n / nthreads);
+    const uintptr_t span = ((hi - lo) / 4096 / nthreads + 1) * 4096;
+    for (int t = 1; t < nthreads; ++t) th.emplace_back(work, lo + span * t < hi ? lo + span * t : hi, lo + span * (t + 1) < hi ? lo + span * (t + 1) : hi);
+    work(lo, lo + span < hi ? lo + span : hi);
     for (auto &t : th) t.join();
 }
 

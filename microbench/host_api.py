@@ -13,12 +13,16 @@ import jpegx  # noqa: E402
 import pipeline  # noqa: E402
 
 
+LAST_RUNS = []
+
+
 def best(fn, n=3):
     ts = []
     for _ in range(n):
         t0 = time.perf_counter()
         out = fn()
         ts.append(time.perf_counter() - t0)
+    LAST_RUNS[:] = ts
     return min(ts), out
 
 
@@ -49,13 +53,14 @@ def main():
                                          quantization=pipeline.QuantizationMethod("qtable"))
             pipeline.compress_band(band, cfg)                      # warm-up (allocations, clocks)
             tc, blob = best(lambda: pipeline.compress_band(band, cfg))
-            td, rec = best(lambda: pipeline.decompress_band(blob, cfg))
+            td, rec = best(lambda: pipeline.decompress_band(blob, cfg), 5)
+            td_runs = "/".join("%.1f" % (t * 1e3) for t in LAST_RUNS)
             tu, rec8 = best(lambda: pipeline.decompress_band_u8(blob, cfg))
             assert np.array_equal(rec8, rec)
             nblk = (size // bs // 8) ** 2
             err = float(np.abs(rec - band64).mean())
-            print("%-6s %-6s block_size %d: compress_band %.2f ms (%.1f Mblocks/s, %d bytes), decompress_band %.1f ms (uint8 result: %.2f ms), "
-                  "mean abs error %.2f" % (kind, band.dtype, bs, tc * 1e3, nblk / tc / 1e6, len(blob), td * 1e3, tu * 1e3, err), flush=True)
+            print("%-6s %-6s block_size %d: compress_band %.2f ms (%.1f Mblocks/s, %d bytes), decompress_band %.1f ms (five calls: %s; uint8 result: %.2f ms), "
+                  "mean abs error %.2f" % (kind, band.dtype, bs, tc * 1e3, nblk / tc / 1e6, len(blob), td * 1e3, td_runs, tu * 1e3, err), flush=True)
 
 
 def image():
