@@ -553,6 +553,42 @@ def entropy_block_sizes(zz):
         dws.free()
 
 
+def forward_u8_block_sizes(plane, block_size=1, mode="qtable", param=0.0):
+    """What compress_band's first two launches leave behind for a uint8 plane: the coefficient stream, the bytes of every
+    block's code string as the forward kernel itself counts them, the stream's total and the error flag of the scan
+    (the library's internal entries; test and measurement hook, not part of include/jpegx.h)."""
+    a = np.ascontiguousarray(plane, dtype=np.uint8)
+    hh, ww = a.shape
+    if block_size not in (1, 2, 4) or hh % (8 * block_size) or ww % (8 * block_size):
+        raise JpegxError("uint8 plane of multiples of 8 * block_size expected")
+    H, W = hh // block_size, ww // block_size
+    nblocks = (H // 8) * (W // 8)
+    L = lib()
+    L.jpegx_internal_entropy_views.argtypes = [ctypes.c_void_p, ctypes.c_longlong, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p)]
+    L.jpegx_internal_entropy_views.restype = None
+    L.jpegx_internal_forward_u8_sized.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_ssize_t, ctypes.c_int, ctypes.c_int, ctypes.c_double,
+                                                  ctypes.c_uint, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    L.jpegx_internal_forward_u8_sized.restype = ctypes.c_int
+    L.jpegx_internal_entropy_scan.argtypes = [ctypes.c_longlong, ctypes.c_void_p, ctypes.c_void_p]
+    L.jpegx_internal_entropy_scan.restype = ctypes.c_int
+    din, dzz, dws = DeviceBuffer(a.nbytes), DeviceBuffer(nblocks * 128), DeviceBuffer(L.jpegx_entropy_workspace_bytes(nblocks))
+    try:
+        din.upload(a)
+        bb, wb = ctypes.c_void_p(), ctypes.c_void_p()
+        L.jpegx_internal_entropy_views(dws.ptr, nblocks, ctypes.byref(bb), ctypes.byref(wb))
+        check(L.jpegx_internal_forward_u8_sized(din.ptr, H, W, ww, block_size, mode_of(mode), float(param), 0, dzz.ptr, bb, wb, None), "forward_u8_sized")
+        check(L.jpegx_internal_entropy_scan(nblocks, dws.ptr, None), "entropy_scan")
+        tot = ctypes.c_ulonglong(0)
+        rc = L.jpegx_entropy_total(dws.ptr, ctypes.byref(tot), None)
+        sizes = np.empty(nblocks, dtype=np.uint32)
+        check(L.jpegx_entropy_block_sizes(dws.ptr, nblocks, sizes.ctypes.data, None), "jpegx_entropy_block_sizes")
+        return dzz.download((H // 8, W // 8, 64), np.int16), sizes, int(tot.value), rc
+    finally:
+        din.free()
+        dzz.free()
+        dws.free()
+
+
 _ELEM_OF = {np.dtype(np.uint8): 1, np.dtype(np.int32): 4, np.dtype(np.int64): 8}
 _pyapi = ctypes.pythonapi
 _pyapi.PyBytes_FromStringAndSize.restype = ctypes.py_object

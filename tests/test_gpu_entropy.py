@@ -60,6 +60,32 @@ def test_compress_plane_all_on_device(gpu):
     assert gpu.compress_plane(a, 2, "qtable") == oracle.rle_bytestream(oracle.forward_f32(pooled, "qtable"))
 
 
+@pytest.mark.parametrize("kind,bs,mode,param", [("noise", 1, "qtable", 0.0), ("smooth", 1, "qtable", 0.0), ("smooth", 2, "qtable", 0.0),
+                                               ("noise", 4, "divide", 3.0), ("smooth", 1, "none", 0.0), ("smooth", 1, "discard", 4.0)])
+def test_forward_kernel_sizes_its_own_blocks(gpu, kind, bs, mode, param):
+    """compress_band's forward kernel counts the entropy stage's bits per block from its registers (two coefficients per
+    instruction, chain codes decided by the wave): same coefficients as the plain kernel, same sizes as the sizes pass
+    over the stream -- which test_device_block_sizes_follow_from_the_reference_tuples pins to the reference's step-7
+    tuples -- and the scan behind it writes total and error flag without the workspace having been cleared."""
+    a = gpu.synth.generate_plane(kind, 256 * bs, 512 * bs, seed=11).astype(np.uint8)
+    zz, sizes, total, rc = gpu.forward_u8_block_sizes(a, bs, mode, param)
+    pooled = oracle.mean_pool(a.astype(np.float32), bs).astype(np.float32) if bs > 1 else a.astype(np.float32)
+    want = oracle.forward_f32(pooled, mode, param)
+    assert np.array_equal(zz, want)
+    ref_sizes = gpu.entropy_block_sizes(want)
+    assert np.array_equal(sizes, ref_sizes)
+    assert rc == 0 and total == int(ref_sizes.sum()) == len(oracle.rle_bytestream(want))
+    if kind == "smooth" and mode in ("qtable", "discard"):
+        assert (np.abs(want.reshape(-1, 64)) > 0).sum(axis=1).min() < 20         # long zero runs: chain codes were counted
+
+
+def test_band_of_more_than_one_scan_chunk(gpu):
+    """4096 x 4112: 263 168 blocks = 4112 waves, one more than a scan chunk holds -- the two-level scan behind the forward
+    kernel's sizes (flag bit masked out of the waves' totals) instead of the single-launch form."""
+    a = gpu.synth.generate_plane("noise", 4096, 4112, seed=3).astype(np.uint8)
+    assert gpu.compress_plane(a, 1, "qtable") == oracle.rle_bytestream(oracle.forward_f32(a.astype(np.float32), "qtable"))
+
+
 @pytest.mark.parametrize("case", CASES)
 def test_device_block_sizes_follow_from_the_reference_tuples(gpu, golden, case):
     """k_rle_sizes against the reference's own step-7 output (tests/golden rle_*): the bytes of every block
