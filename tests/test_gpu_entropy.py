@@ -151,6 +151,27 @@ def test_device_entropy_decoder_large_and_adversarial(gpu, kind):
     assert np.array_equal(gpu.entropy_decode_gpu(b"\x00" * 300, 300), np.zeros((300, 64), np.int16))
 
 
+def test_decoder_state_stays_clean_across_streams_of_different_lengths(gpu):
+    """The segmented decoder keeps its status blocks and exit words zero from call to call by itself (no memset launch per
+    call) and its other arrays move with the segment count: a short stream's arrays must not end up where a later,
+    longer stream keeps its exit words (they did once: the state has an allocation of its own since).  Streams of
+    1 ... 4097 blocks, twice round, refused streams in between, everything on the same pooled working set."""
+    rng = np.random.default_rng(12)
+    streams = []
+    for nblocks in (1, 2, 63, 64, 65, 1000, 4097, 3, 5, 200):
+        z = (rng.integers(-40, 41, (nblocks, 64)) * (rng.random((nblocks, 64)) < 0.2)).astype(np.int16)
+        z[0, :] = rng.integers(-16383, 16384, 64)
+        streams.append((z, oracle.rle_bytestream(z)))
+    for rep in range(2):
+        for z, blob in streams:
+            assert np.array_equal(gpu.entropy_decode_gpu(blob, z.shape[0]), z), (rep, z.shape[0])
+            if z.shape[0] in (65, 200):                    # a refused stream leaves the state clean as well
+                with pytest.raises(gpu.JpegxError):
+                    gpu.entropy_decode_gpu(blob[:-1], z.shape[0])
+                with pytest.raises(gpu.JpegxError):
+                    gpu.entropy_decode_gpu(blob, z.shape[0] + 1)
+
+
 def test_device_entropy_decoder_rejects_what_the_host_parser_rejects(gpu):
     z = np.zeros((4, 64), np.int16)
     z[:, 3] = 5
