@@ -2,7 +2,7 @@
 # Round-3 evidence, final kernels: run on the GPU box from the repo root, one part per gpurun call
 #   gpurun --timeout 1100 -- 'bash profiles/collect_r03_final.sh A'      (traces: bench, entropy stage, host API)
 #   gpurun --timeout 1100 -- 'bash profiles/collect_r03_final.sh B'      (counter passes, never together with a trace)
-# then locally: python profiles/summarize.py r03_forward gpurun_out/fin k_forward_fused_strip
+# then locally: python profiles/summarize.py r03_forward gpurun_out/fin/p k_forward_fused_strip
 #               python profiles/summarize_pmc.py r03 gpurun_out/fin/pmc
 #               python profiles/summarize_trace.py r03_entropy_stage_kernels gpurun_out/fin/entropy_kt  (and the others)
 R=gpurun_out/fin; mkdir -p $R
