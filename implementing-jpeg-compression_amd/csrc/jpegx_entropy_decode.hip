@@ -6,7 +6,9 @@
 // parsed, which is why the reference (and libjpegx's host parser, jpegx_host.cpp) walk it sequentially.
 // What the format does guarantee is that every block ends with a zero byte -- the 8-bit end marker plus the
 // zero padding to the next byte boundary always leave the last byte of a block 0x00 -- so a block can only
-// start at position 0 or right behind a 0x00 byte.  That turns the sequential walk into parallel work:
+// start at position 0 or right behind a 0x00 byte.  That turns the sequential walk into parallel work.  Two schemes
+// live in this file: the segmented one of round 3 (second half: three launches, what the host pipeline runs) and round
+// 2's whole-stream scheme, kept as the fallback for streams the segment tables do not fit, which works like this:
 //   1. candidates  every position 0 or behind a 0x00 byte, compacted in stream order (count + scan + scatter);
 //   2. parse       one thread per candidate parses ONE block from there and records at which candidate the
 //                  next block would start (false candidates -- zero bytes inside a block's amplitude bits --
@@ -14,7 +16,7 @@
 //   3. jump tables J_k[c] = the candidate 4^k blocks behind candidate c (radix-4 pointer jumping, log4(nblocks) passes);
 //   4. starts      block i starts at the candidate reached from position 0 by following the base-4 digits of i;
 //   5. decode      lane per block, values into an LDS tile, coalesced 1 KiB stores into the zigzag stream.
-// Steps 1-4 read the stream twice and touch ~1.4 candidates per block; the result equals the host parser's.
+// Steps 1-4 read the stream twice and touch one to two candidates per block; the result equals the host parser's.
 // One difference on DAMAGED input: the host parser skips the padding bits unread, so a stream whose padding has
 // been tampered with still parses there, while here the block behind it is not found (its start is not behind a
 // 0x00 byte) and the stream is refused; the callers (decompress_band) then take the host parser.  The encoder
