@@ -944,7 +944,7 @@ int levels_for(long long nblocks)          // base-4 digits of the largest block
 }
 
 // ---- segmented scheme (round 3) ----------------------------------------------------------------------------------
-SegPlan seg_plan(size_t nbytes, long long nblocks)
+SegPlan seg_plan(size_t nbytes, long long nblocks, int level)
 {
     SegPlan p;
     // One wave per segment and one parse per candidate: the segment should hold about 46 candidates, so that a 65th
@@ -957,6 +957,11 @@ SegPlan seg_plan(size_t nbytes, long long nblocks)
     int k = (int)(46.0 / per_byte / 256.0 + 0.5);
     const char *force = getenv("JPEGX_DECODE_SEG");                          // A/B runs
     if (force && *force) k = atoi(force) / 256;
+    // second try: a segment of the first overflowed its tables -- a stretch of the stream far denser in blocks than the
+    // average (flat regions of a busy picture: three bytes per block).  256-byte segments hold at most 128 candidates
+    // unless blocks are single bytes; that costs waves (four times as many for a stream of 20-byte blocks), not a host
+    // round trip and the whole-stream scheme
+    if (level >= 1) k = 1;
     k = k < 1 ? 1 : (k > 16 ? 16 : k);
     p.seg = 256 * k;
     p.cmax = 128;                    // candidates a segment's tables hold (a power of two): two and a half times the average

@@ -480,20 +480,24 @@ int jpegx_host_compress_image(const void *const *h_planes, int nbands, int elem_
 
 namespace {
 // bytes already on the device (slot.d_in, padded) -> int16 stream in slot.d_zz; the caller holds the pool.
-// general = false: the segmented scheme (jpegx_entropy_decode.hip, round 3) -- five launches whose workspace depends
-// on the stream's length only, no host round trip; decode_status afterwards may answer DECODE_RETRY_GENERAL for a
-// stream its tables do not fit.  general = true: the pointer-jumping scheme over the whole stream, which reads the
-// candidate count back in the middle.
+// level 0: the segmented scheme (jpegx_entropy_decode.hip, round 3) -- three launches whose workspace depends on the
+// stream's length only, no host round trip; decode_status afterwards may answer DECODE_RETRY_GENERAL ("next level") for a
+// stream whose densest stretch overflows a segment's tables.  level 1: the same with 256-byte segments.  level 2: the
+// pointer-jumping scheme over the whole stream, which reads the candidate count back in the middle.
 constexpr int DECODE_RETRY_GENERAL = 1;
 
-int decode_on_device(BandSlot &slot, size_t nbytes, long long nblocks, hipStream_t st, bool general)
+thread_local int t_last_decode_level = -1;      // which scheme took the last stream on this thread (tests)
+
+int decode_on_device(BandSlot &slot, size_t nbytes, long long nblocks, hipStream_t st, int level)
 {
     int rc;
     if ((rc = slot.d_zz.ensure((size_t)nblocks * 128))) return rc;
-    const jpegx_decode::SegPlan plan = jpegx_decode::seg_plan(nbytes, nblocks);
     const char *force = getenv("JPEGX_DECODE_GENERAL");    // tests / A-B runs: the general scheme from the start
-    if (force && *force && *force != '0') general = true;
-    if (!general && plan.ok) {
+    if (force && *force && *force != '0') level = 2;
+    if (level == 1 && jpegx_decode::seg_plan(nbytes, nblocks, 0).seg == 256) level = 2;      // the first try had the smallest segments already
+    const jpegx_decode::SegPlan plan = jpegx_decode::seg_plan(nbytes, nblocks, level);
+    t_last_decode_level = level;
+    if (level < 2 && plan.ok) {
         if ((rc = slot.d_seg.ensure(plan.ws_bytes)) || (rc = slot.d_seg_state.ensure(plan.state_bytes))) return rc;
         bool fresh = slot.d_seg_state.p != slot.seg_clean || slot.d_seg_state.cap != slot.seg_clean_cap;
         if (const char *ff = getenv("JPEGX_DECODE_FRESH")) fresh = fresh || (*ff && *ff != '0');      // tests: clear the state on every call
@@ -521,7 +525,7 @@ int decode_on_device(BandSlot &slot, size_t nbytes, long long nblocks, hipStream
 }
 
 // after the stream has been synchronised: JPEGX_OK, an error, or DECODE_RETRY_GENERAL
-int decode_status(BandSlot &slot, bool general)
+int decode_status(BandSlot &slot)
 {
     unsigned head[16] = {0};
     const bool seg = slot.seg_parity >= 0;
@@ -534,7 +538,6 @@ int decode_status(BandSlot &slot, bool general)
             if (FILE *f = fopen(dump, "wb")) { fwrite(raw.data(), 1, raw.size(), f); fclose(f); }
         }
     }
-    (void)general;
     if (seg && head[2] != 0) return DECODE_RETRY_GENERAL;
     if (head[1] != 0) return fail(JPEGX_E_INVALID, "entropy stream is not a sequence of well-formed blocks (device decoder)");
     return JPEGX_OK;
@@ -553,14 +556,14 @@ int check_decompress_shape(const uint8_t *h_bytes, size_t nbytes, int H, int W, 
 // upload + device entropy decoding + fused inverse (clamp, SubSampling.invert) of one band into slot.d_out
 // ([H*bs][dev_pitch] bytes), all on `st`
 int enqueue_back(BandSlot &slot, const uint8_t *h_bytes, size_t nbytes, int H, int W, int bs, int mode, double param,
-                 ptrdiff_t dev_pitch, hipStream_t st, bool general)
+                 ptrdiff_t dev_pitch, hipStream_t st, int level)
 {
     const long long nblocks = (long long)(H / 8) * (W / 8);
     int rc;
     if ((rc = slot.d_in.ensure(nbytes + 16)) || (rc = slot.d_out.ensure((size_t)H * bs * dev_pitch))) return rc;
     HP_TRY(hipMemsetAsync(static_cast<uint8_t *>(slot.d_in.p) + (nbytes & ~(size_t)3), 0, 16 + (nbytes & 3), st));   // zero tail (whole dwords)
     HP_TRY(hipMemcpyAsync(slot.d_in.p, h_bytes, nbytes, hipMemcpyHostToDevice, st));
-    if ((rc = decode_on_device(slot, nbytes, nblocks, st, general))) return rc;
+    if ((rc = decode_on_device(slot, nbytes, nblocks, st, level))) return rc;
     return jpegx_inverse_fused_u8_inflated(static_cast<const int16_t *>(slot.d_zz.p), H, W, mode, param, 0, bs,
                                            static_cast<uint8_t *>(slot.d_out.p), dev_pitch, st);
 }
@@ -583,12 +586,12 @@ static int decompress_plane_locked(DevicePool *pool, const uint8_t *h_bytes, siz
     hipStream_t st = pool->stream;
     BandSlot &slot = pool->slot[0];
     BackgroundTouch touch(h_out, fresh_out ? (size_t)H * bs * out_pitch : 0);       // a fresh result array: fault its pages in meanwhile
-    for (int general = 0; general < 2; ++general) {
-        if ((rc = enqueue_back(slot, h_bytes, nbytes, H, W, bs, mode, param, out_pitch, st, general != 0))) return rc;
+    for (int level = 0; level < 3; ++level) {      // planned segments, 256-byte segments, the whole-stream scheme
+        if ((rc = enqueue_back(slot, h_bytes, nbytes, H, W, bs, mode, param, out_pitch, st, level))) return rc;
         touch.wait();
         HP_TRY(hipMemcpyAsync(h_out, slot.d_out.p, (size_t)H * bs * out_pitch, hipMemcpyDeviceToHost, st));
         HP_TRY(hipStreamSynchronize(st));
-        if ((rc = decode_status(slot, general != 0)) != DECODE_RETRY_GENERAL) return rc;
+        if ((rc = decode_status(slot)) != DECODE_RETRY_GENERAL) return rc;
     }
     return fail(JPEGX_E_INVALID, "device decoder: no scheme took the stream");
 }
@@ -665,15 +668,16 @@ int jpegx_host_decompress_image(const uint8_t *const *h_bytes, const size_t *nby
     const size_t out_span = interleave ? (size_t)rows * out_pitch : (size_t)nbands * rows * out_pitch;
     BackgroundTouch touch(h_out, out_span);
     auto drain = [&]() { (void)hipStreamSynchronize(pool->aux[0]); (void)hipStreamSynchronize(pool->aux[1]); };
-    bool general[MAX_BANDS] = {};                           // bands the segmented decoder handed back
-    for (int attempt = 0; attempt < 2; ++attempt) {
+    int level[MAX_BANDS] = {};                              // per band: planned segments, 256-byte segments, the whole-stream scheme
+    bool done[MAX_BANDS] = {};
+    for (int attempt = 0; attempt < 3; ++attempt) {
         for (int k = 0; k < nbands; ++k) {
             hipStream_t st = pool->aux[k & 1];
-            if (attempt && !general[k]) {                    // this band is done: only the packing below waits for it again
+            if (done[k]) {                                   // this band is done: only the packing below waits for it again
                 if (interleave && hipEventRecord(pool->ev[k], st) != hipSuccess) { drain(); return fail(JPEGX_E_HIP, "hipEventRecord failed"); }
                 continue;
             }
-            if ((rc = enqueue_back(pool->slot[k], h_bytes[k], nbytes[k], H, W, bs, mode, param, dev_pitch, st, general[k]))) { drain(); return rc; }
+            if ((rc = enqueue_back(pool->slot[k], h_bytes[k], nbytes[k], H, W, bs, mode, param, dev_pitch, st, level[k]))) { drain(); return rc; }
             if (!interleave) {
                 if (hipMemcpy2DAsync(h_out + (size_t)k * rows * out_pitch, (size_t)out_pitch, pool->slot[k].d_out.p, (size_t)dev_pitch,
                                      (size_t)cols, (size_t)rows, hipMemcpyDeviceToHost, st) != hipSuccess) {
@@ -704,15 +708,18 @@ int jpegx_host_decompress_image(const uint8_t *const *h_bytes, const size_t *nby
         HP_TRY(hipStreamSynchronize(pool->aux[1]));
         bool again = false;
         for (int k = 0; k < nbands; ++k) {
-            if (attempt && !general[k]) continue;
-            rc = decode_status(pool->slot[k], general[k]);
-            if (rc == DECODE_RETRY_GENERAL) { general[k] = true; again = true; }
+            if (done[k]) continue;
+            rc = decode_status(pool->slot[k]);
+            if (rc == DECODE_RETRY_GENERAL) { ++level[k]; again = true; }
             else if (rc) return rc;
+            else done[k] = true;
         }
         if (!again) return JPEGX_OK;
     }
     return fail(JPEGX_E_INVALID, "device decoder: no scheme took the stream");
 }
+
+extern "C" int jpegx_internal_last_decode_level(void) { return t_last_decode_level; }
 
 // bytes -> int16 [nblocks][64] on the device, host arrays in and out (what jpegx_host_entropy_decode does on the CPU)
 int jpegx_host_entropy_decode_gpu(const uint8_t *h_bytes, size_t nbytes, long long nblocks, int16_t *h_zz)
@@ -730,11 +737,11 @@ int jpegx_host_entropy_decode_gpu(const uint8_t *h_bytes, size_t nbytes, long lo
     if ((rc = slot.d_in.ensure(nbytes + 16))) return rc;
     HP_TRY(hipMemsetAsync(static_cast<uint8_t *>(slot.d_in.p) + (nbytes & ~(size_t)3), 0, 16 + (nbytes & 3), st));
     HP_TRY(hipMemcpyAsync(slot.d_in.p, h_bytes, nbytes, hipMemcpyHostToDevice, st));
-    for (int general = 0; general < 2; ++general) {
-        if ((rc = decode_on_device(slot, nbytes, nblocks, st, general != 0))) return rc;
+    for (int level = 0; level < 3; ++level) {
+        if ((rc = decode_on_device(slot, nbytes, nblocks, st, level))) return rc;
         HP_TRY(hipMemcpyAsync(h_zz, slot.d_zz.p, (size_t)nblocks * 128, hipMemcpyDeviceToHost, st));
         HP_TRY(hipStreamSynchronize(st));
-        if ((rc = decode_status(slot, general != 0)) != DECODE_RETRY_GENERAL) return rc;
+        if ((rc = decode_status(slot)) != DECODE_RETRY_GENERAL) return rc;
     }
     return fail(JPEGX_E_INVALID, "device decoder: no scheme took the stream");
 }

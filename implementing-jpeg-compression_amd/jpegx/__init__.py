@@ -553,6 +553,14 @@ def entropy_block_sizes(zz):
         dws.free()
 
 
+def last_decode_level():
+    """Which scheme took the last stream the device decoder saw on this thread: 0 segments sized from the stream's average,
+    1 the smallest segments (second try), 2 the whole-stream scheme (test hook, not part of include/jpegx.h)."""
+    L = lib()
+    L.jpegx_internal_last_decode_level.restype = ctypes.c_int
+    return int(L.jpegx_internal_last_decode_level())
+
+
 def forward_u8_block_sizes(plane, block_size=1, mode="qtable", param=0.0):
     """What compress_band's first two launches leave behind for a uint8 plane: the coefficient stream, the bytes of every
     block's code string as the forward kernel itself counts them, the stream's total and the error flag of the scan

@@ -151,6 +151,26 @@ def test_device_entropy_decoder_large_and_adversarial(gpu, kind):
     assert np.array_equal(gpu.entropy_decode_gpu(b"\x00" * 300, 300), np.zeros((300, 64), np.int16))
 
 
+def test_flat_regions_in_a_busy_stream_take_the_second_try_not_the_whole_stream_scheme(gpu):
+    """Segments are sized from the stream's AVERAGE block length; a stretch of three-byte blocks (a flat region: only the
+    DC coefficient) inside a stream of long blocks holds several hundred block starts per segment -- more than its tables
+    do.  The decoder then goes again with 256-byte segments before it falls back to the whole-stream scheme (and its
+    host round trip); single-byte blocks (all coefficients zero) overflow those too."""
+    rng = np.random.default_rng(21)
+    busy = rng.integers(-300, 300, (3000, 64)).astype(np.int16)
+    flat = np.zeros((2500, 64), np.int16)
+    flat[:, 0] = rng.integers(100, 1000, 2500)
+    z = np.concatenate([busy[:1500], flat, busy[1500:]])
+    blob = oracle.rle_bytestream(z)
+    assert np.array_equal(gpu.entropy_decode_gpu(blob, z.shape[0]), z)
+    assert gpu.last_decode_level() == 1
+    assert np.array_equal(gpu.entropy_decode_gpu(oracle.rle_bytestream(busy), busy.shape[0]), busy)
+    assert gpu.last_decode_level() == 0
+    black = np.concatenate([busy[:1500], np.zeros((4000, 64), np.int16), busy[1500:]])
+    assert np.array_equal(gpu.entropy_decode_gpu(oracle.rle_bytestream(black), black.shape[0]), black)
+    assert gpu.last_decode_level() == 2
+
+
 def test_decoder_state_stays_clean_across_streams_of_different_lengths(gpu):
     """The segmented decoder keeps its status blocks and exit words zero from call to call by itself (no memset launch per
     call) and its other arrays move with the segment count: a short stream's arrays must not end up where a later,
