@@ -305,7 +305,6 @@ __global__ __launch_bounds__(64) void k_dec_blocks(const unsigned *__restrict__ 
 namespace seg {
 
 typedef __attribute__((address_space(1))) unsigned gu32;
-typedef __attribute__((address_space(1))) unsigned long long gu64;
 #define JPEGX_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 
 constexpr int REACH = 192;                 // a block is at most 185 bytes: the chain enters a segment within its first REACH bytes
@@ -462,13 +461,6 @@ __device__ __forceinline__ unsigned xcd_run_segment(unsigned i)
 {
     const unsigned j = i >> 3, x = i & 7u;
     return ((((j >> RUN_LOG) << 3) + x) << RUN_LOG) + (j & ((1u << RUN_LOG) - 1u));
-}
-
-__device__ __forceinline__ unsigned wave_sum(unsigned v)
-{
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
-    return v;
 }
 
 // 16-byte pieces [first, first + n) of the stream -> LDS as big-endian dwords, up to PER pieces per thread, all loads in flight at once
