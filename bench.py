@@ -285,16 +285,16 @@ def config_u8(jpegx, kind, iters, verify, planes=16):
     # second pass over the stream, k_rle_sizes, is gone); an internal entry of the library, not part of include/jpegx.h
     L = jpegx.lib()
     ws = jpegx.DeviceBuffer(int(L.jpegx_entropy_workspace_bytes(blocks)))
-    bb, wb_ = ctypes.c_void_p(), ctypes.c_void_p()
-    L.jpegx_internal_entropy_views.argtypes = [ctypes.c_void_p, ctypes.c_longlong, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p)]
+    bb, wb_, hb = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+    L.jpegx_internal_entropy_views.argtypes = [ctypes.c_void_p, ctypes.c_longlong] + [ctypes.POINTER(ctypes.c_void_p)] * 3
     L.jpegx_internal_entropy_views.restype = None
-    L.jpegx_internal_entropy_views(ws.ptr, blocks, ctypes.byref(bb), ctypes.byref(wb_))
+    L.jpegx_internal_entropy_views(ws.ptr, blocks, ctypes.byref(bb), ctypes.byref(wb_), ctypes.byref(hb))
     L.jpegx_internal_forward_u8_sized.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_ssize_t, ctypes.c_int, ctypes.c_int, ctypes.c_double,
-                                                  ctypes.c_uint, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+                                                  ctypes.c_uint, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     L.jpegx_internal_forward_u8_sized.restype = ctypes.c_int
 
     def fwd_sized():
-        jpegx.check(L.jpegx_internal_forward_u8_sized(u8.ptr, H, n, n, 1, jpegx.Q_QTABLE, 0.0, 0, zz.ptr, bb, wb_, None), "forward_u8_sized")
+        jpegx.check(L.jpegx_internal_forward_u8_sized(u8.ptr, H, n, n, 1, jpegx.Q_QTABLE, 0.0, 0, zz.ptr, bb, wb_, hb, None), "forward_u8_sized")
     fwd()
     ms_f = _timed_launches(jpegx, fwd, iters)
     ms_s = _timed_launches(jpegx, fwd_sized, iters)

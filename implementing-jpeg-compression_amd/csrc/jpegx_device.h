@@ -313,15 +313,16 @@ __device__ __forceinline__ void census(unsigned long long *counters, unsigned lo
 // Two coefficients per instruction where the ISA allows: |.| by v_pk_sub / v_pk_max, "non-zero" by v_pk_min_u16 with
 // 1, the 64-bit non-zero mask by doubling an accumulator (word k's flags land in bits k and 16 + k: even and odd
 // coefficients apart, interleaved afterwards), bit lengths through v_ffbh_u32 (which says -1 for zero: the sum is
-// corrected by the number of zeros).
-__device__ __forceinline__ unsigned rle_block_bytes(const unsigned (&pk)[32], bool &bad)
+// corrected by the number of zeros).  half: what the two-lanes-per-block emitter needs to start a lane at coefficient 32.
+__device__ __forceinline__ unsigned rle_block_bytes(const unsigned (&pk)[32], bool &bad, unsigned &half)
 {
     typedef short s16x2 __attribute__((ext_vector_type(2)));
     typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-    int sumf = 0;
+    int sumf = 0, sumf_lo = 0;
     unsigned acc[2] = {0u, 0u}, any = 0u;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
+        if (h == 1) sumf_lo = sumf;
 #pragma unroll
         for (int k = 15; k >= 0; --k) {
             const s16x2 x = __builtin_bit_cast(s16x2, pk[16 * h + k]);
@@ -351,7 +352,7 @@ __device__ __forceinline__ unsigned rle_block_bytes(const unsigned (&pk)[32], bo
     const unsigned long long M = ((unsigned long long)m[1] << 32) | m[0];
     // chain codes: one per fifteen zeros in front of a non-zero (see chain_count in jpegx_entropy.hip); rare enough to be
     // decided by the wave
-    unsigned chains = 0;
+    unsigned chains = 0, chains_lo = 0;
     {
         const unsigned long long z = ~M;
         const unsigned long long r2 = z & (z << 1), r4 = r2 & (r2 << 2), r8 = r4 & (r4 << 4);
@@ -361,9 +362,13 @@ __device__ __forceinline__ unsigned rle_block_bytes(const unsigned (&pk)[32], bo
             const unsigned long long r45 = r30 & (r15 << 30);
             const unsigned long long r60 = r30 & (r30 << 30);
             chains = (unsigned)(__popcll((r15 << 1) & M) + __popcll((r30 << 1) & M) + __popcll((r45 << 1) & M) + __popcll((r60 << 1) & M));
+            chains_lo = (unsigned)(__popc((unsigned)(r15 << 1) & m[0]) + __popc((unsigned)(r30 << 1) & m[0]));      // runs of 45 do not end below 32 ... but 30 do
         }
     }
     const unsigned bits = 8u + sum_bl + 9u * nnz + 8u * chains;
+    // for the emitter's second lane: the bits of the codes of coefficients 0..31, and 1 + the last non-zero among them
+    const unsigned bits_lo = (32u * 31u - (unsigned)sumf_lo) + 9u * (unsigned)__popc(acc[0]) + 8u * chains_lo;
+    half = bits_lo | ((m[0] ? 32u - (unsigned)__clz((int)m[0]) : 0u) << 12);
     return (bits + 7u) >> 3;
 }
 

@@ -44,6 +44,7 @@ struct Workspace {
     unsigned *wave_bytes;            // [nw rounded up to SCAN_CHUNK]
     unsigned *wave_off;              // [nw rounded up to SCAN_CHUNK], offset inside the wave's chunk
     unsigned *block_bytes;           // [nblocks]
+    unsigned *half_info;             // [nblocks] bits of the codes of coefficients 0..31 | (1 + last non-zero among them) << 12 (forward kernels that size their own blocks)
 };
 
 __host__ __device__ inline size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
@@ -63,6 +64,8 @@ __host__ __device__ inline Workspace carve(void *ws, long long nblocks)
     w.wave_off = reinterpret_cast<unsigned *>(p + off);
     off += (size_t)nchunks * SCAN_CHUNK * 4;
     w.block_bytes = reinterpret_cast<unsigned *>(p + off);
+    off += align16((size_t)nblocks * 4);
+    w.half_info = reinterpret_cast<unsigned *>(p + off);
     return w;
 }
 
@@ -70,7 +73,7 @@ size_t workspace_bytes(long long nblocks)
 {
     const long long nw = (nblocks + 63) / 64;
     const long long nchunks = (nw + SCAN_CHUNK - 1) / SCAN_CHUNK;
-    return align16(16 + (size_t)(nchunks + 1) * 8) + 2 * (size_t)nchunks * SCAN_CHUNK * 4 + align16((size_t)nblocks * 4);
+    return align16(16 + (size_t)(nchunks + 1) * 8) + 2 * (size_t)nchunks * SCAN_CHUNK * 4 + 2 * align16((size_t)nblocks * 4);
 }
 
 // the wave's 64 x 128 B of coefficients -> swizzled LDS tile (LDS-DMA, as in k_inverse_fused)
@@ -329,6 +332,97 @@ __global__ __launch_bounds__(64) void k_rle_emit(const int16_t *__restrict__ zz,
     }
 }
 
+// k_rle_emit with TWO lanes per block (workgroup of two waves: wave 0 emits the codes of coefficients 0..31, wave 1 those
+// of 32..63, from the bit offset and the last non-zero the forward kernel left in half_info).  A single 4096 x 4096
+// band is 4096 such workgroups -- a handful per CU -- and the time of this kernel is then the length of one lane's
+// dependent walk: 32 steps instead of 64.
+__global__ __launch_bounds__(128) void k_rle_emit2(const int16_t *__restrict__ zz, int nblk, const void *ws,
+                                                   unsigned char *__restrict__ out)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char lds[EMIT_STAGE_BYTES];
+    unsigned *stage = reinterpret_cast<unsigned *>(lds);
+    const Workspace W = carve(const_cast<void *>(ws), nblk);
+    if (*W.error != 0) return;                           // an amplitude beyond 15 bits: nothing is emitted (see k_rle_emit)
+    const int t = threadIdx.x, lane = t & 63, half = t >> 6, g0 = blockIdx.x * 64, g = g0 + lane;
+    {
+        // the wave's 64 x 128 B of coefficients -> swizzled LDS tile, four LDS-DMA pieces per wave
+        const int row0 = lane >> 3, c = (lane & 7) ^ (lane >> 3);
+        const int last = nblk - 1 - g0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int piece = half * 4 + i, row = min(piece * 8 + row0, last);
+            const unsigned char *src = reinterpret_cast<const unsigned char *>(zz) + (size_t)(g0 + row) * 128 + c * 16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(lds + piece * 1024), 16, 0, 2);
+        }
+    }
+    const unsigned mine = (g < nblk) ? W.block_bytes[g] : 0u;
+    const unsigned info = (g < nblk) ? W.half_info[g] : 0u;
+    unsigned char *gdst = out + W.chunk_off[blockIdx.x / SCAN_CHUNK] + W.wave_off[blockIdx.x];   // workgroup-uniform
+    __syncthreads();
+    unsigned w[16];                                      // the lane's half of the block: coefficients 32 half .. 32 half + 31
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const u32x4 q = *reinterpret_cast<const u32x4 *>(lds + tile_off(lane, half * 4 + c));
+        w[c * 4 + 0] = q.x; w[c * 4 + 1] = q.y; w[c * 4 + 2] = q.z; w[c * 4 + 3] = q.w;
+    }
+    unsigned incl = mine;                                 // in-wave inclusive scan of the block sizes (both waves: same numbers)
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned v = __shfl_up(incl, d);
+        if (lane >= d) incl += v;
+    }
+    const unsigned total = __shfl(incl, 63);
+    const unsigned skew = (unsigned)(reinterpret_cast<uintptr_t>(gdst) & 15u);
+    const unsigned end = skew + total;                    // bytes of staging in use
+    __syncthreads();                                      // every lane has its half block in registers
+    for (unsigned c = t * 16u; c < end + 16u; c += 128u * 16u)
+        *reinterpret_cast<u32x4 *>(reinterpret_cast<unsigned char *>(stage) + c) = u32x4{0u, 0u, 0u, 0u};
+    __syncthreads();
+
+    if (g < nblk) {
+        unsigned o = 8u * (skew + incl - mine) + (half ? (info & 0xFFFu) : 0u);   // bit offset of the lane's first code
+        auto put = [&](unsigned code, int n) {            // n <= 24 bits, MSB-first at bit offset o
+            const unsigned long long v = (unsigned long long)code << (64 - n - (int)(o & 31u));
+            atomicOr(&stage[o >> 5], (unsigned)(v >> 32));
+            const unsigned lo = (unsigned)v;
+            if (lo) atomicOr(&stage[(o >> 5) + 1], lo);
+            o += (unsigned)n;
+        };
+        int prev = half ? (int)(info >> 12) - 1 - 32 : -1;            // last non-zero in front, relative to the lane's first coefficient
+#pragma unroll
+        for (int p = 0; p < 32; ++p) {
+            const int q = (p & 1) ? ((int)w[p >> 1] >> 16) : (int)(short)(w[p >> 1] & 0xFFFFu);
+            if (q != 0) {
+                int run = p - prev - 1;
+                while (run >= 15) { put(0xF0u, 8); run -= 15; }           // (15, 0, 0): fifteen zeros
+                const unsigned mag = (unsigned)(q < 0 ? -q : q);
+                const int bl = bit_length(mag);
+                const unsigned hdr = ((unsigned)run << 4) | (unsigned)(bl + 1);   // 4-bit run, 4-bit size
+                put((hdr << (bl + 1)) | ((q > 0 ? 1u : 0u) << bl) | mag, 9 + bl);  // + sign + magnitude
+                prev = p;
+            }
+        }
+        // EOB (8 zero bits) and the zero padding to the byte boundary are already there
+    }
+    __syncthreads();
+
+    unsigned char *gbase = gdst - skew;                   // 16-byte aligned
+    for (unsigned c = t * 16u; c < end; c += 128u * 16u) {
+        u32x4 x = *reinterpret_cast<const u32x4 *>(reinterpret_cast<const unsigned char *>(stage) + c);
+        x.x = __builtin_bswap32(x.x); x.y = __builtin_bswap32(x.y);
+        x.z = __builtin_bswap32(x.z); x.w = __builtin_bswap32(x.w);
+        if (c >= skew && c + 16u <= end) {
+            __builtin_nontemporal_store(x, reinterpret_cast<u32x4 *>(gbase + c));
+        } else {
+            const unsigned wd[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+            for (unsigned k = 0; k < 16u; ++k)
+                if (c + k >= skew && c + k < end) gbase[c + k] = (unsigned char)(wd[k >> 2] >> (8u * (k & 3u)));
+        }
+    }
+}
+
 int fail(int code, const char *msg)
 {
     jpegx_internal_set_error(msg);
@@ -377,11 +471,24 @@ int jpegx_entropy_sizes(const int16_t *d_zz, long long nblocks, void *d_workspac
 }
 
 // internal: where the forward kernels that size their own blocks put the sizes, and the scans behind them
-void jpegx_internal_entropy_views(void *d_workspace, long long nblocks, unsigned **block_bytes, unsigned **wave_bytes)
+void jpegx_internal_entropy_views(void *d_workspace, long long nblocks, unsigned **block_bytes, unsigned **wave_bytes, unsigned **half_info)
 {
     const Workspace W = carve(d_workspace, nblocks);
     *block_bytes = W.block_bytes;
     *wave_bytes = W.wave_bytes;
+    *half_info = W.half_info;
+}
+
+// the emitter for streams whose forward kernel left half_info behind: two lanes per block
+int jpegx_internal_entropy_emit2(const int16_t *d_zz, long long nblocks, const void *d_workspace, uint8_t *d_out, jpegx_stream_t stream)
+{
+    int rc = check_args(d_zz, nblocks, d_workspace);
+    if (rc) return rc;
+    if (!d_out) return fail(JPEGX_E_INVALID, "null output pointer");
+    const int nblk = (int)nblocks;
+    hipLaunchKernelGGL(k_rle_emit2, dim3((nblk + 63) / 64), dim3(128), 0, (hipStream_t)stream, d_zz, nblk, d_workspace, d_out);
+    HIP_TRY(hipGetLastError());
+    return JPEGX_OK;
 }
 
 int jpegx_internal_entropy_scan(long long nblocks, void *d_workspace, jpegx_stream_t stream)

@@ -990,7 +990,7 @@ template <bool DC_EXACT, int BS, bool NT, bool SIZES = false>
 __global__ __launch_bounds__(64) JPEGX_U8_OCC void k_forward_fused_u8(const unsigned char *__restrict__ in, size_t pitch, int wb,
                                                          int nblk, QuantParams prm, int16_t *__restrict__ out,
                                                          unsigned long long *counters, unsigned *__restrict__ block_bytes = nullptr,
-                                                         unsigned *__restrict__ wave_bytes = nullptr)
+                                                         unsigned *__restrict__ wave_bytes = nullptr, unsigned *__restrict__ half_info = nullptr)
 {
     constexpr int ROWS = 8 * BS;                       // input rows of the wave's blocks
     constexpr int ROW_BYTES = 64 * 8 * BS;             // bytes of one input row in LDS (64 blocks)
@@ -1182,9 +1182,10 @@ __global__ __launch_bounds__(64) JPEGX_U8_OCC void k_forward_fused_u8(const unsi
 
     if (SIZES) {
         bool bad;
-        unsigned bytes = rle_block_bytes(pk, bad);
+        unsigned half;
+        unsigned bytes = rle_block_bytes(pk, bad, half);
         if (!valid) { bytes = 0; bad = false; }
-        if (valid) block_bytes[g0 + lane] = bytes;
+        if (valid) { block_bytes[g0 + lane] = bytes; half_info[g0 + lane] = half; }
         unsigned sum = bytes;
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d);
@@ -1528,7 +1529,7 @@ int jpegx_forward_fused(const float *d_in, int H, int W, ptrdiff_t pitch, int mo
 }
 
 static int forward_u8_common(const uint8_t *d_in, int H, int W, ptrdiff_t pitch, int bs, int mode, double param,
-                             unsigned flags, int16_t *d_out, unsigned *block_bytes, unsigned *wave_bytes, jpegx_stream_t stream)
+                             unsigned flags, int16_t *d_out, unsigned *block_bytes, unsigned *wave_bytes, unsigned *half_info, jpegx_stream_t stream)
 {
     if (bs != 1 && bs != 2 && bs != 4) return fail(JPEGX_E_UNSUPPORTED, "uint8 forward supports block_size 1, 2 and 4");
     int rc = check_plane(d_in, d_out, H, W, pitch / bs, 1);
@@ -1552,7 +1553,7 @@ static int forward_u8_common(const uint8_t *d_in, int H, int W, ptrdiff_t pitch,
     QuantParams qa = qp;
     scale_for_aan(&qa);
 #define JPEGX_LU8K(DC, BSV, NTV, SZ) \
-    hipLaunchKernelGGL((k_forward_fused_u8<DC, BSV, NTV, SZ>), grid, block, 0, st, d_in, (size_t)pitch, wb, nblk, qa, d_out, g_counters, block_bytes, wave_bytes)
+    hipLaunchKernelGGL((k_forward_fused_u8<DC, BSV, NTV, SZ>), grid, block, 0, st, d_in, (size_t)pitch, wb, nblk, qa, d_out, g_counters, block_bytes, wave_bytes, half_info)
 #define JPEGX_LU8(DC, BSV) \
     do { if (sizes) { if (nt) JPEGX_LU8K(DC, BSV, true, true); else JPEGX_LU8K(DC, BSV, false, true); } \
          else { if (nt) JPEGX_LU8K(DC, BSV, true, false); else JPEGX_LU8K(DC, BSV, false, false); } } while (0)
@@ -1568,15 +1569,15 @@ static int forward_u8_common(const uint8_t *d_in, int H, int W, ptrdiff_t pitch,
 int jpegx_forward_fused_u8(const uint8_t *d_in, int H, int W, ptrdiff_t pitch, int bs, int mode, double param,
                            unsigned flags, int16_t *d_out, jpegx_stream_t stream)
 {
-    return forward_u8_common(d_in, H, W, pitch, bs, mode, param, flags, d_out, nullptr, nullptr, stream);
+    return forward_u8_common(d_in, H, W, pitch, bs, mode, param, flags, d_out, nullptr, nullptr, nullptr, stream);
 }
 
 // internal (jpegx_internal.h): the same with the entropy stage's block sizes written into its workspace on the way
 int jpegx_internal_forward_u8_sized(const uint8_t *d_in, int H, int W, ptrdiff_t pitch, int bs, int mode, double param, unsigned flags,
-                                    int16_t *d_out, unsigned *block_bytes, unsigned *wave_bytes, jpegx_stream_t stream)
+                                    int16_t *d_out, unsigned *block_bytes, unsigned *wave_bytes, unsigned *half_info, jpegx_stream_t stream)
 {
-    if (!block_bytes || !wave_bytes) return fail(JPEGX_E_INVALID, "null workspace views");
-    return forward_u8_common(d_in, H, W, pitch, bs, mode, param, flags, d_out, block_bytes, wave_bytes, stream);
+    if (!block_bytes || !wave_bytes || !half_info) return fail(JPEGX_E_INVALID, "null workspace views");
+    return forward_u8_common(d_in, H, W, pitch, bs, mode, param, flags, d_out, block_bytes, wave_bytes, half_info, stream);
 }
 int jpegx_host_forward_fused_f64(const double *h_in, int H, int W, int mode, double param, unsigned flags, int16_t *h_out)
 {

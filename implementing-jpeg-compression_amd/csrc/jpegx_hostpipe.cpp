@@ -28,8 +28,9 @@
 extern "C" void jpegx_internal_set_error(const char *msg);
 // the uint8 forward kernels sizing their own blocks for the entropy stage (jpegx_forward.hip, jpegx_entropy.hip)
 extern "C" int jpegx_internal_forward_u8_sized(const uint8_t *d_in, int H, int W, ptrdiff_t pitch, int bs, int mode, double param, unsigned flags,
-                                               int16_t *d_out, unsigned *block_bytes, unsigned *wave_bytes, jpegx_stream_t stream);
-extern "C" void jpegx_internal_entropy_views(void *d_workspace, long long nblocks, unsigned **block_bytes, unsigned **wave_bytes);
+                                               int16_t *d_out, unsigned *block_bytes, unsigned *wave_bytes, unsigned *half_info, jpegx_stream_t stream);
+extern "C" void jpegx_internal_entropy_views(void *d_workspace, long long nblocks, unsigned **block_bytes, unsigned **wave_bytes, unsigned **half_info);
+extern "C" int jpegx_internal_entropy_emit2(const int16_t *d_zz, long long nblocks, const void *d_workspace, uint8_t *d_out, jpegx_stream_t stream);
 extern "C" int jpegx_internal_entropy_scan(long long nblocks, void *d_workspace, jpegx_stream_t stream);
 
 namespace {
@@ -89,6 +90,7 @@ struct BandSlot {
     size_t seg_clean_cap = 0;
     unsigned seg_calls = 0;
     int seg_parity = -1;          // status block of the last decode (-1: the general scheme ran, status in d_ws)
+    bool sized = false;           // compress: the forward kernel sized the blocks itself (half_info is there)
 };
 
 struct DevicePool {
@@ -285,11 +287,12 @@ int enqueue_front(DevicePool *pool, BandSlot &slot, uint8_t *stage, const void *
     if (fused_pool) {
         // the forward kernel sizes its blocks from the registers (RunLengthEncoding's bit counts): no second pass over the
         // stream, and the scan that follows writes the workspace's head itself -- two launches, no memset
-        unsigned *block_bytes = nullptr, *wave_bytes = nullptr;
-        jpegx_internal_entropy_views(slot.d_ws.p, nblocks, &block_bytes, &wave_bytes);
+        unsigned *block_bytes = nullptr, *wave_bytes = nullptr, *half_info = nullptr;
+        jpegx_internal_entropy_views(slot.d_ws.p, nblocks, &block_bytes, &wave_bytes, &half_info);
         rc = jpegx_internal_forward_u8_sized(static_cast<const uint8_t *>(slot.d_in.p), H, W, WW, bs, mode, param, 0,
-                                             static_cast<int16_t *>(slot.d_zz.p), block_bytes, wave_bytes, st);
+                                             static_cast<int16_t *>(slot.d_zz.p), block_bytes, wave_bytes, half_info, st);
         if (rc) return rc;
+        slot.sized = true;                 // the emitter may go with two lanes per block
         return jpegx_internal_entropy_scan(nblocks, slot.d_ws.p, st);
     } else {
         // any other block_size: SubSampling on the device in float64 (exact sum, one division), then the
@@ -301,7 +304,15 @@ int enqueue_front(DevicePool *pool, BandSlot &slot, uint8_t *stage, const void *
                                          static_cast<int16_t *>(slot.d_zz.p), st);
     }
     if (rc) return rc;
+    slot.sized = false;
     return jpegx_entropy_sizes(static_cast<const int16_t *>(slot.d_zz.p), nblocks, slot.d_ws.p, st);
+}
+
+// the emit launch that fits how the band's sizes were made
+int enqueue_emit(BandSlot &slot, long long nblocks, uint8_t *d_out, hipStream_t st)
+{
+    return slot.sized ? jpegx_internal_entropy_emit2(static_cast<const int16_t *>(slot.d_zz.p), nblocks, slot.d_ws.p, d_out, st)
+                      : jpegx_entropy_emit(static_cast<const int16_t *>(slot.d_zz.p), nblocks, slot.d_ws.p, d_out, st);
 }
 
 // JPEGX_TRACE=1: time stamps of the image jobs' host-side steps on stderr (where does a job's wall time go)
@@ -357,8 +368,7 @@ int jpegx_host_compress_begin(const void *h_plane, int elem_size, int H, int W, 
     if ((rc = jpegx_entropy_total(slot.d_ws.p, &total, st))) return bail(rc);      // synchronises
     if ((rc = slot.d_out.ensure(total ? (size_t)total : 1))) return bail(rc);
     const long long nblocks = (long long)(H / 8) * (W / 8);
-    if ((rc = jpegx_entropy_emit(static_cast<const int16_t *>(slot.d_zz.p), nblocks, slot.d_ws.p,
-                                 static_cast<uint8_t *>(slot.d_out.p), st)))
+    if ((rc = enqueue_emit(slot, nblocks, static_cast<uint8_t *>(slot.d_out.p), st)))
         return bail(rc);
     pool->open = true;
     pool->out_bytes = (size_t)total;
@@ -445,8 +455,7 @@ int jpegx_host_compress_image(const void *const *h_planes, int nbands, int elem_
         // the emit kernel needs only the device-side offsets: enqueue it now, the destination comes later
         BandSlot &slot = pool->slot[k];
         if ((rc = slot.d_out.ensure(total ? (size_t)total : 1)) ||
-            (rc = jpegx_entropy_emit(static_cast<const int16_t *>(slot.d_zz.p), nblocks, slot.d_ws.p, static_cast<uint8_t *>(slot.d_out.p),
-                                     pool->aux[k & 1]))) {
+            (rc = enqueue_emit(slot, nblocks, static_cast<uint8_t *>(slot.d_out.p), pool->aux[k & 1]))) {
             drain();
             return rc;
         }

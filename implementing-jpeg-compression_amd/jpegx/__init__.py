@@ -572,19 +572,19 @@ def forward_u8_block_sizes(plane, block_size=1, mode="qtable", param=0.0):
     H, W = hh // block_size, ww // block_size
     nblocks = (H // 8) * (W // 8)
     L = lib()
-    L.jpegx_internal_entropy_views.argtypes = [ctypes.c_void_p, ctypes.c_longlong, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p)]
+    L.jpegx_internal_entropy_views.argtypes = [ctypes.c_void_p, ctypes.c_longlong] + [ctypes.POINTER(ctypes.c_void_p)] * 3
     L.jpegx_internal_entropy_views.restype = None
     L.jpegx_internal_forward_u8_sized.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_ssize_t, ctypes.c_int, ctypes.c_int, ctypes.c_double,
-                                                  ctypes.c_uint, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+                                                  ctypes.c_uint, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     L.jpegx_internal_forward_u8_sized.restype = ctypes.c_int
     L.jpegx_internal_entropy_scan.argtypes = [ctypes.c_longlong, ctypes.c_void_p, ctypes.c_void_p]
     L.jpegx_internal_entropy_scan.restype = ctypes.c_int
     din, dzz, dws = DeviceBuffer(a.nbytes), DeviceBuffer(nblocks * 128), DeviceBuffer(L.jpegx_entropy_workspace_bytes(nblocks))
     try:
         din.upload(a)
-        bb, wb = ctypes.c_void_p(), ctypes.c_void_p()
-        L.jpegx_internal_entropy_views(dws.ptr, nblocks, ctypes.byref(bb), ctypes.byref(wb))
-        check(L.jpegx_internal_forward_u8_sized(din.ptr, H, W, ww, block_size, mode_of(mode), float(param), 0, dzz.ptr, bb, wb, None), "forward_u8_sized")
+        bb, wb, hb = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+        L.jpegx_internal_entropy_views(dws.ptr, nblocks, ctypes.byref(bb), ctypes.byref(wb), ctypes.byref(hb))
+        check(L.jpegx_internal_forward_u8_sized(din.ptr, H, W, ww, block_size, mode_of(mode), float(param), 0, dzz.ptr, bb, wb, hb, None), "forward_u8_sized")
         check(L.jpegx_internal_entropy_scan(nblocks, dws.ptr, None), "entropy_scan")
         tot = ctypes.c_ulonglong(0)
         rc = L.jpegx_entropy_total(dws.ptr, ctypes.byref(tot), None)
