@@ -23,5 +23,6 @@ for P in A B C; do
     run_pass inv_u8_$P "$CTR" python3 microbench/ab_forward.py v=0x0 --direction inverse --out-type u8 --planes 16 --rounds 3 --iters 5
     run_pass fwd_f32_$P "$CTR" python3 microbench/ab_forward.py v=0x1 --planes 16 --rounds 3 --iters 5
     run_pass entropy_$P "$CTR" python3 microbench/entropy_stage.py
+    run_pass band_jobs_$P "$CTR" python3 microbench/host_api.py      # what compress_band / decompress_band launch for single bands: the sized forward, k_rle_emit2, the decoder
 done
 ls $R
