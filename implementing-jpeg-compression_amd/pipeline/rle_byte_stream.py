@@ -67,30 +67,32 @@ class RleBytestream(AlgorithmStep):
         window, have, pos = 0, 0, 0                 # upcoming bits as an int, how many of them, next byte to load
 
         def take(n):
+            """(value, bits there were): a read that runs past the end returns the bits that are left -- the reference's
+            bitarray slices come back short (rle_byte_stream.py:20-24) -- and int('', base=2) of none at all raises."""
             nonlocal window, have, pos
             while have < n and pos < len(data):
                 window = (window << 8) | data[pos]
                 pos += 1
                 have += 8
-            if have < n:                            # past the end the reference's slices just come back short
-                window <<= n - have
-                have = n
-            have -= n
+            got = min(n, have)
+            have -= got
             value = window >> have
             window &= (1 << have) - 1
-            return value
+            return value, got
 
         while pos < len(data) or have > 0:
-            run, size = take(4), take(4)
+            (run, got_run), (size, got_size) = take(4), take(4)
+            if got_run == 0 or got_size == 0:
+                raise ValueError("the stream ends inside a code's header")
             if run == 0 and size == 0:
                 window, have = 0, 0                 # drop the padding: the next block starts on a byte
                 out.append((0, 0))
             elif run == 15 and size == 0:
                 out.append((15, 0, 0))
             else:
-                if size <= 1:                       # the reference fails here too: int('', base=2) (no amplitude bits)
+                bits, got = take(size)
+                if got <= 1:                        # the reference fails here too: int('', base=2) (no amplitude bits)
                     raise ValueError("run-length code ({}, {}) has no amplitude bits".format(run, size))
-                bits = take(size)
-                magnitude = bits & ((1 << (size - 1)) - 1)
-                out.append((run, size, magnitude if bits >> (size - 1) else -magnitude))
+                magnitude = bits & ((1 << (got - 1)) - 1)
+                out.append((run, size, magnitude if bits >> (got - 1) else -magnitude))
         return out

@@ -60,6 +60,11 @@ def lib():
                                         ctypes.POINTER(ctypes.c_uint8), ctypes.c_longlong,
                                         ctypes.POINTER(ctypes.c_uint32)]
         L.jo_rle_bytestream.restype = ctypes.c_longlong
+        L.jo_rle_stream_tuples.argtypes = [ctypes.POINTER(ctypes.c_uint8), ctypes.c_longlong, ctypes.POINTER(c_int), ctypes.c_longlong]
+        L.jo_rle_stream_tuples.restype = ctypes.c_longlong
+        L.jo_rle_tuples_decode.argtypes = [ctypes.POINTER(c_int), ctypes.c_longlong, ctypes.c_longlong, c_int,
+                                           ctypes.POINTER(ctypes.c_int32)]
+        L.jo_rle_tuples_decode.restype = ctypes.c_longlong
         for n in ("jo_table_dct_matrix", "jo_table_dct_normalized", "jo_table_norm_diag"):
             getattr(L, n).restype = dp
         for n in ("jo_table_qtable", "jo_table_zigzag"):
@@ -221,3 +226,50 @@ def rle_bytestream(zz, want_block_bytes=False):
     got = lib().jo_rle_bytestream(_p(z, ctypes.c_int16), nblocks, n, _p(out, ctypes.c_uint8), total, None)
     assert got == total
     return (out.tobytes(), sizes) if want_block_bytes else out.tobytes()
+
+
+class RleStreamError(ValueError):
+    """What the reference raises on a damaged stream: ValueError (int('', 2), reshape) or BadRleCodeError."""
+
+
+def _triples(tuples):
+    flat = np.zeros((len(tuples), 3), dtype=np.int32)
+    for i, t in enumerate(tuples):
+        flat[i, :len(t)] = t
+    return flat
+
+
+def rle_stream_tuples(blob):
+    """RleBytestream.invert (pipeline/rle_byte_stream.py:61-88): the stream's tuples, end markers as (0, 0)."""
+    b = np.frombuffer(bytes(blob), dtype=np.uint8)
+    cap = b.size + 1                                   # a tuple takes at least a byte, the first may sit in a partial read
+    buf = np.zeros((cap, 3), dtype=np.int32)
+    k = lib().jo_rle_stream_tuples(_p(b, ctypes.c_uint8) if b.size else None, b.size, _p(buf, ctypes.c_int), cap)
+    if k < 0:
+        raise RleStreamError("bad code in the stream (%d)" % k)
+    return [(0, 0) if (r == 0 and s_ == 0) else (r, s_, a) for r, s_, a in buf[:k].tolist()]
+
+
+def rle_tuples_decode(tuples, nblocks, n=64):
+    """RunLengthEncoding.invert (pipeline/run_length_encoding.py:66-79) -> (nblocks, n) int32."""
+    flat = np.ascontiguousarray(_triples(tuples))
+    out = np.zeros((nblocks, n), dtype=np.int32)
+    got = lib().jo_rle_tuples_decode(_p(flat, ctypes.c_int), len(flat), nblocks, n, _p(out, ctypes.c_int32))
+    if got < 0:
+        raise RleStreamError("the blocks' values do not fill a (%d, %d) array" % (nblocks, n))
+    return out
+
+
+def rle_decode(blob, nblocks, n=64):
+    """Steps 8 + 7 backwards on a byte stream -> (nblocks, n) int32; RleStreamError where the reference raises."""
+    b = np.frombuffer(bytes(blob), dtype=np.uint8)
+    cap = b.size + 1
+    buf = np.zeros((cap, 3), dtype=np.int32)
+    k = lib().jo_rle_stream_tuples(_p(b, ctypes.c_uint8) if b.size else None, b.size, _p(buf, ctypes.c_int), cap)
+    if k < 0:
+        raise RleStreamError("bad code in the stream (%d)" % k)
+    out = np.zeros((nblocks, n), dtype=np.int32)
+    got = lib().jo_rle_tuples_decode(_p(buf, ctypes.c_int), k, nblocks, n, _p(out, ctypes.c_int32))
+    if got < 0:
+        raise RleStreamError("the blocks' values do not fill a (%d, %d) array" % (nblocks, n))
+    return out

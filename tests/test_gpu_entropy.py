@@ -120,15 +120,18 @@ def test_emit_after_a_flagged_sizes_pass_writes_nothing(gpu):
 
 @pytest.mark.parametrize("case", CASES)
 def test_device_entropy_decoder_matches_the_host_parser(gpu, golden, case):
-    """The parallel decoder (block starts recovered from the zero byte that ends every block, pointer doubling,
-    lane-per-block decode) returns exactly what the sequential host parser returns, on every golden stream."""
+    """The parallel decoder (block starts recovered from the zero byte that ends every block, way marks, four lanes per
+    block) returns exactly what the oracle's decoder (the reference's steps 8 and 7 backwards, restated; pinned in
+    test_oracle_golden.py) and the sequential host parser return, on every golden stream."""
     c = golden(case)
     for suffix, _, _ in MODES:
         zz = c["zz_" + suffix]
         blob = oracle.rle_bytestream(zz)
         n = zz.shape[0] * zz.shape[1]
-        assert np.array_equal(gpu.entropy_decode_gpu(blob, n).reshape(zz.shape), zz), (case, suffix)
-        assert np.array_equal(gpu.entropy_decode(blob, n).reshape(zz.shape), zz)
+        want = oracle.rle_decode(blob, n)
+        assert np.array_equal(want.reshape(zz.shape), zz)
+        assert np.array_equal(gpu.entropy_decode_gpu(blob, n), want), (case, suffix)
+        assert np.array_equal(gpu.entropy_decode(blob, n), want)
 
 
 @pytest.mark.parametrize("kind", ["noise", "smooth"])
@@ -236,6 +239,18 @@ def test_device_and_host_decoders_agree_on_damaged_streams(gpu):
                 host = gpu.entropy_decode(blob, n)
             except gpu.JpegxError:
                 host = None
+            # the judge: the oracle's restatement of the reference's decoder.  What the host parser (hence the device)
+            # accepts, the reference accepts with the same values; the reverse does not hold -- the reference reads
+            # short at the end of the stream and drops codes behind the last end marker (test_oracle_golden.py)
+            try:
+                ref = oracle.rle_decode(blob, n)
+            except oracle.RleStreamError:
+                ref = None
+            assert not (host is not None and ref is None), (trial, n)
+            if host is not None:
+                assert np.array_equal(host, ref), (trial, n)
+            seen["reference accepts, host parser refuses"] = seen.get("reference accepts, host parser refuses", 0) + \
+                (ref is not None and host is None)
             try:
                 dev = gpu.entropy_decode_gpu(blob, n)
             except gpu.JpegxError:
@@ -247,6 +262,7 @@ def test_device_and_host_decoders_agree_on_damaged_streams(gpu):
             else:
                 seen["both refuse" if host is None else "device stricter"] += 1
     assert seen["equal"] >= 10 and seen["both refuse"] >= 100 and seen["device stricter"] <= 5, seen
+    assert seen["reference accepts, host parser refuses"] <= 12, seen
 
 
 def test_segmented_and_general_decoders_agree(gpu, monkeypatch):

@@ -223,3 +223,183 @@ def test_block_size_3_case_from_the_reference(golden):
     assert np.array_equal(dct, c["dct"])
     for suffix, mode, param in MODES:
         assert np.array_equal(oracle.zigzag_plane(oracle.quant_plane(dct, mode, param)), c["zz_" + suffix].astype(np.float64))
+
+
+# ---- the way back (steps 8 and 7 inverted): the oracle's decoder pinned ---------------------------------------------
+def _from_bits(s):
+    s = s.replace(" ", "")
+    assert len(s) % 8 == 0
+    return bytes(int(s[i:i + 8], 2) for i in range(0, len(s), 8))
+
+
+def test_rle_stream_decoder_known_answers():
+    """The bit strings the reference's tests expect from RleBytestream.execute (tests/RLE_tests.py:98-122), read
+    backwards, and the round trips that file asserts for RleBytestream.invert (:124-139, :182-196) -- with the encoding
+    direction pinned above, invert(execute(x)) == x pins the decoder on those tuple lists."""
+    assert oracle.rle_stream_tuples(_from_bits("0100 0011 110" + "0" * 13)) == [(4, 3, 2), (0, 0)]
+    assert oracle.rle_stream_tuples(_from_bits("1111 0000" + "0" * 8)) == [(15, 0, 0), (0, 0)]
+    trips = [
+        ([(15, 0, 0), (15, 0, 0), (0, 2, 1), (0, 0)], 31),                                   # :124-130
+        ([(1, 2, -1), (0, 3, -2), (8, 3, -3), (8, 5, -15), (0, 0)], 21),                    # :132-138
+        ([(14, 4, 7), (0, 0)], 15),                                                         # :182-188
+        ([(14, 4, 7), (0, 0), (0, 0), (15, 0, 0), (0, 2, 1), (0, 0)], 16),                  # :190-196
+    ]
+    for x, n in trips:
+        nblocks = sum(1 for t in x if len(t) == 2)
+        z = oracle.rle_tuples_decode(x, nblocks, n)                    # RunLengthEncoding.invert: the values
+        assert [t for blk in z for t in oracle.rle_block_tuples(blk)] == x      # ... whose tuples are x again
+        blob = oracle.rle_bytestream(z.reshape(nblocks, 1, n))
+        assert oracle.rle_stream_tuples(blob) == x
+        assert np.array_equal(oracle.rle_decode(blob, nblocks, n), z)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_rle_decoder_on_every_golden_stream(golden, case):
+    """RunLengthEncoding.invert of the reference's own step-7 tuples is the golden zigzag array (the reference ran that
+    direction when the fixtures were made: `izz_*` continues from it); the oracle's decoder gives the same from the
+    tuples and from the bytes."""
+    c = golden(case)
+    for suffix, _, _ in MODES:
+        zz = c["zz_" + suffix].reshape(-1, 64)
+        want = reference_tuples(c["rle_" + suffix])
+        assert np.array_equal(oracle.rle_tuples_decode(want, len(zz)), zz), (case, suffix)
+        blob = oracle.rle_bytestream(zz.reshape(len(zz), 1, 64))
+        assert oracle.rle_stream_tuples(blob) == want
+        assert np.array_equal(oracle.rle_decode(blob, len(zz)), zz)
+
+
+def test_rle_decoder_fails_where_the_reference_does():
+    """Error behaviour read off the reference's code (it cannot be run: bitarray): int('', 2) for a code of size 1 and
+    for the headers (1..14, 0); reshape for a wrong number of values.  And what it lets pass: codes behind the last end
+    marker (an unfinished block is never yielded, run_length_encoding.py:91-97), damaged padding bits (stepped over
+    unread, rle_byte_stream.py:26-28), a block longer than 64 values as long as the TOTAL fits (run_length_encoding.py:
+    37-38: `[0] * negative` is empty)."""
+    z = np.zeros((3, 64), np.int16)
+    z[0, 3], z[1, 0], z[2, 63] = 5, -7, 1
+    good = oracle.rle_bytestream(z.reshape(3, 1, 64))
+    assert np.array_equal(oracle.rle_decode(good, 3), z)
+    with pytest.raises(oracle.RleStreamError):
+        oracle.rle_decode(good, 2)                                        # a block too many for the plane
+    with pytest.raises(oracle.RleStreamError):
+        oracle.rle_decode(good, 4)
+    with pytest.raises(oracle.RleStreamError):
+        oracle.rle_decode(good + b"\x00", 3)                              # one more (empty) block behind the plane
+    with pytest.raises(oracle.RleStreamError):
+        oracle.rle_decode(_from_bits("0000 0001 1" + "0" * 7) + good, 4)  # size 1: sign bit only
+    with pytest.raises(oracle.RleStreamError):
+        oracle.rle_decode(_from_bits("0011 0000") + good, 3)              # (3, 0)
+    # the last byte cut off: two bits of the last end marker are left, and a read at the end of the stream returns the
+    # bits there are (run '0000', size '00'): still an end marker.  One byte more and the amplitude has no bits: int('', 2)
+    assert np.array_equal(oracle.rle_decode(good[:-1], 3), z)
+    with pytest.raises(oracle.RleStreamError):
+        oracle.rle_decode(good[:-2], 3)
+    assert np.array_equal(oracle.rle_decode(good + b"\xf0", 3), z)        # a zero chain behind the last end marker: dropped
+    first = oracle.rle_bytestream(z[:1].reshape(1, 1, 64))
+    bits = "".join(format(b, "08b") for b in first)
+    assert bits.endswith("0" * 9)                                         # the block ends '...' + end marker + padding
+    tampered = _from_bits(bits[:-1] + "1") + good[len(first):]
+    assert np.array_equal(oracle.rle_decode(tampered, 3), z)              # a padding bit set: nobody reads it
+    # one block of 128 values (two zero chains short of it, then a value) passes for two blocks of 64
+    long_block = [(15, 0, 0)] * 8 + [(7, 2, 1), (0, 0)]
+    got = oracle.rle_tuples_decode(long_block, 2)
+    assert got.shape == (2, 64) and got[1, 63] == 1 and np.count_nonzero(got) == 1
+
+
+def test_host_mirror_decoder_against_the_oracle_on_damaged_streams():
+    """The product's pure-Python steps 8/7 backwards (pipeline/rle_byte_stream.py, run_length_encoding.py of the package)
+    against the oracle's restatement of the reference on random bytes and damaged well-formed streams: whatever the
+    package accepts the reference accepts too, with the same values; the package is stricter only on streams no encoder
+    writes (codes behind the last end marker, blocks of more than 64 values)."""
+    from pipeline import Configuration
+    from pipeline.rle_byte_stream import RleBytestream
+    from pipeline.run_length_encoding import RunLengthEncoding
+    rng = np.random.default_rng(21)
+    seen = {"equal": 0, "both refuse": 0, "package stricter": 0}
+    for trial in range(300):
+        nb = int(rng.integers(1, 40))
+        cfg = Configuration(width=8 * nb, height=8, block_size=1, dct_size=8)
+        kind = trial % 4
+        zz = (rng.integers(-300, 300, (nb, 64)) * (rng.random((nb, 64)) < rng.random())).astype(np.int16)
+        dmg = bytearray(oracle.rle_bytestream(zz.reshape(nb, 1, 64)))
+        if kind == 0:
+            dmg = bytearray(rng.integers(0, 256, int(rng.integers(1, 600)), dtype=np.uint8).tobytes())
+        elif kind == 1:
+            for _ in range(int(rng.integers(0, 3))):
+                dmg[int(rng.integers(0, len(dmg)))] ^= 1 << int(rng.integers(0, 8))
+        elif kind == 2:
+            dmg = dmg[:int(rng.integers(1, len(dmg) + 1))]
+        else:
+            i = int(rng.integers(0, len(dmg) + 1))
+            dmg[i:i] = rng.integers(0, 256, int(rng.integers(1, 5)), dtype=np.uint8).tobytes()
+        blob = bytes(dmg)
+        try:
+            want = oracle.rle_decode(blob, nb)
+        except oracle.RleStreamError:
+            want = None
+        try:
+            got = np.asarray(RunLengthEncoding(cfg).invert(RleBytestream(cfg).invert(blob))).reshape(nb, 64)
+        except Exception:
+            got = None
+        assert not (got is not None and want is None), trial
+        if got is not None:
+            assert np.array_equal(got, want), trial
+            seen["equal"] += 1
+        else:
+            seen["both refuse" if want is None else "package stricter"] += 1
+    assert seen["equal"] >= 30 and seen["both refuse"] >= 100 and seen["package stricter"] <= 15, seen
+
+
+def test_native_host_parser_against_the_oracle_on_damaged_streams():
+    """jpegx_host_entropy_decode (C++, no device involved: what decompress_band falls back to and what the device
+    decoder is fuzzed against in test_gpu_entropy.py) with the oracle's restatement of the reference as the judge: what
+    it accepts the reference accepts, with the same values.  It refuses more than the reference does, on streams no
+    encoder writes: it wants every header and amplitude whole (the reference reads short at the end of the stream),
+    nothing behind the plane's last block (the reference drops codes that no end marker follows) and at most 64
+    values per block (the reference only checks the total)."""
+    import jpegx
+    z = np.zeros((3, 64), np.int16)
+    z[0, 3], z[1, 0], z[2, 63] = 5, -7, 1
+    good = oracle.rle_bytestream(z.reshape(3, 1, 64))
+    assert np.array_equal(jpegx.entropy_decode(good, 3), z)
+    first = oracle.rle_bytestream(z[:1].reshape(1, 1, 64))
+    bits = "".join(format(b, "08b") for b in first)
+    tampered = _from_bits(bits[:-1] + "1") + good[len(first):]
+    assert np.array_equal(jpegx.entropy_decode(tampered, 3), z)          # padding bits are stepped over unread, as in the reference
+    long_block = oracle.rle_bytestream(oracle.rle_tuples_decode([(15, 0, 0)] * 8 + [(7, 2, 1), (0, 0)], 1, 128).reshape(1, 1, 128))
+    for lenient, n in ((good + b"\xf0", 3), (good[:-1], 3), (long_block, 2)):
+        oracle.rle_decode(lenient, n)                                    # the reference lets these pass ...
+        with pytest.raises(jpegx.JpegxError):
+            jpegx.entropy_decode(lenient, n)                             # ... the native parser does not
+    rng = np.random.default_rng(5)
+    seen = {"equal": 0, "both refuse": 0, "parser stricter": 0}
+    for trial in range(400):
+        nb = int(rng.integers(1, 120))
+        kind = trial % 4
+        zz = (rng.integers(-300, 300, (nb, 64)) * (rng.random((nb, 64)) < rng.random())).astype(np.int16)
+        dmg = bytearray(oracle.rle_bytestream(zz.reshape(nb, 1, 64)))
+        if kind == 0:
+            dmg = bytearray(rng.integers(0, 256, int(rng.integers(1, 2048)), dtype=np.uint8).tobytes())
+        elif kind == 1:
+            for _ in range(int(rng.integers(0, 3))):
+                dmg[int(rng.integers(0, len(dmg)))] ^= 1 << int(rng.integers(0, 8))
+        elif kind == 2:
+            dmg = dmg[:max(1, len(dmg) - int(rng.integers(0, 4)))]
+        else:
+            i = int(rng.integers(0, len(dmg) + 1))
+            dmg[i:i] = rng.integers(0, 256, int(rng.integers(1, 5)), dtype=np.uint8).tobytes()
+        blob = bytes(dmg)
+        try:
+            want = oracle.rle_decode(blob, nb)
+        except oracle.RleStreamError:
+            want = None
+        try:
+            got = jpegx.entropy_decode(blob, nb)
+        except jpegx.JpegxError:
+            got = None
+        assert not (got is not None and want is None), trial
+        if got is not None:
+            assert np.array_equal(got, want), trial
+            seen["equal"] += 1
+        else:
+            seen["both refuse" if want is None else "parser stricter"] += 1
+    assert seen["equal"] >= 40 and seen["both refuse"] >= 100 and seen["parser stricter"] >= 1, seen
