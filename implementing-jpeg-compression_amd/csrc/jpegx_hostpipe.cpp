@@ -208,31 +208,50 @@ bool narrow_rows(const T *src, ptrdiff_t src_pitch, int H, int W, uint8_t *dst, 
 void prefault(uint8_t *p, size_t n)
 {
     if (n < (4u << 20)) return;
-    // What a fresh 128 MiB result array costs is the operating system's (NumPy asks for transparent huge pages: 64 faults
-    // of 2 MiB, ~5 ms on the GPU box for np.empty + one write per page) and none of the ways to pay it early was
-    // measured faster than letting the eight threads that fill the array fault it in (profiles/r03_prefault_ab.txt):
-    // 1 / 2 / 4 / 8 touching threads 16 / 12 / 11.5 / 11 ms per decompress_band call, MADV_POPULATE_WRITE 15 ms,
-    // nothing at all 11 ms -- against 2-3 ms when the allocator hands back pages that are already mapped.
-    static const int mode = [] { const char *e = getenv("JPEGX_PREFAULT"); return e && *e ? atoi(e) : 8; }();   // A/B: threads; -1 populate, -2 huge pages + populate; 0 off
+    // What a fresh result buffer costs is the operating system's, and it depends on the page size (microbench/pagefault.cpp
+    // on the GPU box, profiles/r03_pagefault.txt): 72 MB of 4 KiB pages 8.7 ms touched by one thread, 4.4-5.8 ms by eight
+    // (the faults of one address space serialise on its lock), 0.7 ms as 2 MiB pages touched by eight threads in
+    // interleaved 2 MiB grains.  NumPy asks for huge pages itself (its 128 MiB arrays: 64 faults); a Python bytes object
+    // comes from malloc -> mmap without that advice, so it is given here for the aligned interior of the destination
+    // (transparent_hugepage is in `madvise` mode on these hosts; where it is `never` the call changes nothing).
+    // JPEGX_PREFAULT: touching threads (default 8; 0 = leave the faults to the copy; -1 MADV_POPULATE_WRITE, -2 with huge
+    // pages); JPEGX_PREFAULT_HUGE=0: no advice (A/B, profiles/r03_prefault_ab.txt).
+    static const int mode = [] { const char *e = getenv("JPEGX_PREFAULT"); return e && *e ? atoi(e) : 8; }();
+    static const bool advise = [] { const char *e = getenv("JPEGX_PREFAULT_HUGE"); return !(e && *e == '0'); }();
     if (mode == 0) return;
     const uintptr_t lo = (reinterpret_cast<uintptr_t>(p) + 4095) & ~(uintptr_t)4095, hi = (reinterpret_cast<uintptr_t>(p) + n) & ~(uintptr_t)4095;
     if (hi <= lo) return;
+    {
+        // memory the allocator hands back warm (malloc recycles blocks of up to 32 MiB; a caller's reused buffer) needs
+        // none of this: eight probes of the page tables, and if every probed page is there the threads are not started
+        bool warm = true;
+        for (int k = 0; k < 8 && warm; ++k) {
+            unsigned char vec = 0;
+            const uintptr_t a = lo + (((hi - lo) / 4096) * (uintptr_t)k / 8) * 4096;
+            warm = mincore(reinterpret_cast<void *>(a), 4096, &vec) == 0 && (vec & 1u);
+        }
+        if (warm) return;
+    }
+    const uintptr_t huge = (uintptr_t)2 << 20;
+    const uintptr_t hlo = (lo + huge - 1) & ~(huge - 1), hhi = hi & ~(huge - 1);
+    if ((advise || mode == -2) && hhi > hlo) (void)madvise(reinterpret_cast<void *>(hlo), hhi - hlo, MADV_HUGEPAGE);
     if (mode < 0) {
 #ifndef MADV_POPULATE_WRITE
 #define MADV_POPULATE_WRITE 23      /* Linux 5.14 */
 #endif
-        const uintptr_t hlo = (lo + (2u << 20) - 1) & ~(uintptr_t)((2u << 20) - 1), hhi = hi & ~(uintptr_t)((2u << 20) - 1);
-        if (mode == -2 && hhi > hlo) (void)madvise(reinterpret_cast<void *>(hlo), hhi - hlo, MADV_HUGEPAGE);
         if (madvise(reinterpret_cast<void *>(lo), hi - lo, MADV_POPULATE_WRITE) == 0) return;
     }
     const int nthreads = mode > 0 ? mode : 1;
-    auto work = [&](uintptr_t a, uintptr_t b) {
-        for (uintptr_t o = a; o < b; o += 4096) { volatile uint8_t *q = reinterpret_cast<volatile uint8_t *>(o); *q = 0; }
+    // thread t takes the 2 MiB-aligned grains t, t + nthreads, ...: one fault per grain where huge pages are granted
+    auto work = [&](int t) {
+        for (uintptr_t g = (lo & ~(huge - 1)) + (uintptr_t)t * huge; g < hi; g += huge * (uintptr_t)nthreads) {
+            const uintptr_t a = g < lo ? lo : g, b = g + huge < hi ? g + huge : hi;
+            for (uintptr_t o = a; o < b; o += 4096) { volatile uint8_t *q = reinterpret_cast<volatile uint8_t *>(o); *q = 0; }
+        }
     };
     std::vector<std::thread> th;
-    const uintptr_t span = ((hi - lo) / 4096 / nthreads + 1) * 4096;
-    for (int t = 1; t < nthreads; ++t) th.emplace_back(work, lo + span * t < hi ? lo + span * t : hi, lo + span * (t + 1) < hi ? lo + span * (t + 1) : hi);
-    work(lo, lo + span < hi ? lo + span : hi);
+    for (int t = 1; t < nthreads; ++t) th.emplace_back(work, t);
+    work(0);
     for (auto &t : th) t.join();
 }
 
@@ -383,6 +402,7 @@ int jpegx_host_compress_finish(uint8_t *h_out)
     hipError_t e = hipSuccess;
     if (pool->out_bytes) {
         if (!h_out) e = hipErrorInvalidValue;
+        if (e == hipSuccess) prefault(h_out, pool->out_bytes);      // a fresh bytes object: its pages first (the emit kernel runs meanwhile)
         if (e == hipSuccess) e = hipMemcpyAsync(h_out, pool->slot[0].d_out.p, pool->out_bytes, hipMemcpyDeviceToHost, pool->stream);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(pool->stream);
@@ -679,7 +699,14 @@ int jpegx_host_decompress_image(const uint8_t *const *h_bytes, const size_t *nby
     auto drain = [&]() { (void)hipStreamSynchronize(pool->aux[0]); (void)hipStreamSynchronize(pool->aux[1]); };
     int level[MAX_BANDS] = {};                              // per band: planned segments, 256-byte segments, the whole-stream scheme
     bool done[MAX_BANDS] = {};
+    auto copy_down = [&](int j) -> int {                    // band j's samples to their place in the result, on the band's stream
+        if (hipMemcpy2DAsync(h_out + (size_t)j * rows * out_pitch, (size_t)out_pitch, pool->slot[j].d_out.p, (size_t)dev_pitch,
+                             (size_t)cols, (size_t)rows, hipMemcpyDeviceToHost, pool->aux[j & 1]) != hipSuccess)
+            return fail(JPEGX_E_HIP, "device to host copy failed");
+        return JPEGX_OK;
+    };
     for (int attempt = 0; attempt < 3; ++attempt) {
+        int held = -1;                                       // a band whose copy down is not enqueued yet
         for (int k = 0; k < nbands; ++k) {
             hipStream_t st = pool->aux[k & 1];
             if (done[k]) {                                   // this band is done: only the packing below waits for it again
@@ -688,11 +715,14 @@ int jpegx_host_decompress_image(const uint8_t *const *h_bytes, const size_t *nby
             }
             if ((rc = enqueue_back(pool->slot[k], h_bytes[k], nbytes[k], H, W, bs, mode, param, dev_pitch, st, level[k]))) { drain(); return rc; }
             if (!interleave) {
-                if (hipMemcpy2DAsync(h_out + (size_t)k * rows * out_pitch, (size_t)out_pitch, pool->slot[k].d_out.p, (size_t)dev_pitch,
-                                     (size_t)cols, (size_t)rows, hipMemcpyDeviceToHost, st) != hipSuccess) {
-                    drain();
-                    return fail(JPEGX_E_HIP, "device to host copy failed");
-                }
+                // No copy may be ENQUEUED while the helper thread still writes its zeros into the result's pages (a copy
+                // that landed first would lose one byte per page).  The first band's copy is therefore held back until
+                // the second band's work is in its own stream: the wait then costs nothing the device could notice.
+                if (k == 0 && nbands > 1 && !done[1]) { held = 0; continue; }
+                touch.wait();
+                if (held >= 0 && (rc = copy_down(held))) { drain(); return rc; }
+                held = -1;
+                if ((rc = copy_down(k))) { drain(); return rc; }
             } else if (hipEventRecord(pool->ev[k], st) != hipSuccess) {
                 drain();
                 return fail(JPEGX_E_HIP, "hipEventRecord failed");
@@ -708,6 +738,7 @@ int jpegx_host_decompress_image(const uint8_t *const *h_bytes, const size_t *nby
             }
             uint8_t *packed = static_cast<uint8_t *>(pool->d_packed.p);
             if ((rc = jpegx_interleave_u8(planes, nbands, rows, cols, dev_pitch, packed, (ptrdiff_t)packed_pitch, st))) { drain(); return rc; }
+            touch.wait();                                    // the helper thread's zeros first, then the copy (see above)
             if (hipMemcpy2DAsync(h_out, (size_t)out_pitch, packed, packed_pitch, packed_pitch, (size_t)rows, hipMemcpyDeviceToHost, st) != hipSuccess) {
                 drain();
                 return fail(JPEGX_E_HIP, "device to host copy failed");

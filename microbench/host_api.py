@@ -17,8 +17,14 @@ LAST_RUNS = []
 
 
 def best(fn, n=3):
+    """Best of n calls.  The previous call's result is released BEFORE the clock starts: handing a 128 MiB array or a
+    72 MB bytes object back to the operating system (munmap of touched pages) costs 5-9 ms, and with `out = fn()` alone
+    that release fell inside the next call's timed region (round-3 files written before this fix show it as 11-14 ms
+    calls behind a 3 ms first call)."""
     ts = []
+    out = None
     for _ in range(n):
+        out = None
         t0 = time.perf_counter()
         out = fn()
         ts.append(time.perf_counter() - t0)
@@ -30,21 +36,24 @@ def fresh_result_cost(shape, dtype, n=5):
     """What the operating system charges for a fresh result array of this size, with no codec involved: allocate it and
     touch every page once (ms, median).  decompress_band returns such an array; outliers of its wall time that match
     this figure are the allocator's, not the pipeline's."""
-    ts = []
+    ts, rel = [], []
     for _ in range(n):
         t0 = time.perf_counter()
         a = np.empty(shape, dtype)
         a.reshape(-1)[::4096 // a.itemsize] = 0
-        ts.append((time.perf_counter() - t0) * 1e3)
+        t1 = time.perf_counter()
         del a
-    return sorted(ts)[len(ts) // 2]
+        rel.append((time.perf_counter() - t1) * 1e3)
+        ts.append((t1 - t0) * 1e3)
+    return sorted(ts)[len(ts) // 2], sorted(rel)[len(rel) // 2]
 
 
 def main():
     jpegx.require_device()
     size = 4096
-    print("fresh 4096x4096 result arrays, allocate + touch every page (no codec): int64 %.2f ms, uint8 %.2f ms"
-          % (fresh_result_cost((size, size), np.int64), fresh_result_cost((size, size), np.uint8)), flush=True)
+    (a64, r64), (a8, r8) = fresh_result_cost((size, size), np.int64), fresh_result_cost((size, size), np.uint8)
+    print("fresh 4096x4096 result arrays, no codec: allocate + touch every page int64 %.2f ms, uint8 %.2f ms; release int64 %.2f ms, uint8 %.2f ms"
+          % (a64, a8, r64, r8), flush=True)
     for kind in ("smooth", "noise"):
         band64 = jpegx.synth.generate_plane(kind, size, size, seed=1, dtype=np.int64)
         for bs, band in ((1, band64.astype(np.uint8)), (1, band64), (2, band64.astype(np.uint8)), (2, band64),
