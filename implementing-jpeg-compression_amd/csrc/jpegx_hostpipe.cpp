@@ -653,13 +653,17 @@ int jpegx_host_decompress_plane_i64(const uint8_t *h_bytes, size_t nbytes, int H
     if ((rc = decompress_plane_locked(pool, h_bytes, nbytes, H, W, bs, mode, param, stage, pitch, false))) return rc;
     touch.wait();
     const unsigned hw = std::thread::hardware_concurrency();
-    const int nthreads = ((size_t)rows * cols < (1u << 20)) ? 1 : (hw >= 8 ? 8 : (hw ? (int)hw : 1));
+    static const int want = [] { const char *e = getenv("JPEGX_WIDEN_THREADS"); return e && *e ? atoi(e) : 8; }();      // A/B
+    const int nthreads = ((size_t)rows * cols < (1u << 20)) ? 1 : ((int)hw >= want ? want : (hw ? (int)hw : 1));
+    // non-temporal stores: the array is written once, 8 bytes per sample, and is eight times the size of what is read --
+    // ordinary stores would first READ every line of it for ownership (twice the memory traffic)
     auto work = [&](int y0, int y1) {
         for (int y = y0; y < y1; ++y) {
             const uint8_t *srow = stage + (size_t)y * pitch;
             int64_t *drow = h_out + (size_t)y * cols;
-            for (int x = 0; x < cols; ++x) drow[x] = srow[x];
+            for (int x = 0; x < cols; ++x) __builtin_nontemporal_store((int64_t)srow[x], drow + x);
         }
+        __builtin_ia32_sfence();
     };
     if (nthreads == 1) {
         work(0, rows);
