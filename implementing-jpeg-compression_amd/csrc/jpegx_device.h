@@ -316,28 +316,48 @@ __device__ __forceinline__ void census(unsigned long long *counters, unsigned lo
 // corrected by the number of zeros).  half: what the two-lanes-per-block emitter needs to start a lane at coefficient 32.
 __device__ __forceinline__ unsigned rle_block_bytes(const unsigned (&pk)[32], bool &bad, unsigned &half)
 {
-    typedef short s16x2 __attribute__((ext_vector_type(2)));
-    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
     int sumf = 0, sumf_lo = 0;
     unsigned acc[2] = {0u, 0u}, any = 0u;
+    // Written out instruction by instruction: left to the compiler, min(|a|, 1) on the packed halves becomes two
+    // compares (one of them SDWA), two selects and a byte permute per word, and a guard against clz(0) two more
+    // instructions per coefficient.  Per pair of words here: |.| (v_pk_sub, v_pk_max), the OR of all magnitudes,
+    // v_ffbh_u32 of either half (32 - bit_length; -1 for zero, put right below from the number of zeros), the
+    // non-zero flags of both halves in one v_pk_min_u16 and the doubling accumulator: 19 instructions for four
+    // coefficients.
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         if (h == 1) sumf_lo = sumf;
+        unsigned a_h = 0u;
 #pragma unroll
-        for (int k = 15; k >= 0; --k) {
-            const s16x2 x = __builtin_bit_cast(s16x2, pk[16 * h + k]);
-            const s16x2 neg = s16x2{0, 0} - x;
-            const s16x2 ab = __builtin_elementwise_max(x, neg);
-            const unsigned a = __builtin_bit_cast(unsigned, ab);
-            any |= a;
-            sumf += (int)__builtin_clz(((a & 0xFFFFu) << 1) | 1u) + (int)__builtin_clz(((a >> 16) << 1) | 1u);   // 31 - bit_length each
-            const u16x2 one = __builtin_elementwise_min(__builtin_bit_cast(u16x2, a), u16x2{1, 1});
-            acc[h] = acc[h] + acc[h] + __builtin_bit_cast(unsigned, one);
+        for (int k = 15; k >= 1; k -= 2) {
+            unsigned t0, t1, u0, u1;
+            asm("v_pk_sub_i16 %[t0], 0, %[x0]\n\t"
+                "v_pk_sub_i16 %[t1], 0, %[x1]\n\t"
+                "v_pk_max_i16 %[t0], %[x0], %[t0]\n\t"
+                "v_pk_max_i16 %[t1], %[x1], %[t1]\n\t"
+                "v_or3_b32 %[any], %[any], %[t0], %[t1]\n\t"
+                "v_and_b32 %[u0], 0xffff, %[t0]\n\t"
+                "v_lshrrev_b32 %[u1], 16, %[t0]\n\t"
+                "v_ffbh_u32 %[u0], %[u0]\n\t"
+                "v_ffbh_u32 %[u1], %[u1]\n\t"
+                "v_add3_u32 %[sum], %[sum], %[u0], %[u1]\n\t"
+                "v_and_b32 %[u0], 0xffff, %[t1]\n\t"
+                "v_lshrrev_b32 %[u1], 16, %[t1]\n\t"
+                "v_ffbh_u32 %[u0], %[u0]\n\t"
+                "v_ffbh_u32 %[u1], %[u1]\n\t"
+                "v_add3_u32 %[sum], %[sum], %[u0], %[u1]\n\t"
+                "v_pk_min_u16 %[t0], %[t0], %[ones]\n\t"
+                "v_pk_min_u16 %[t1], %[t1], %[ones]\n\t"
+                "v_lshl_add_u32 %[acc], %[acc], 1, %[t0]\n\t"
+                "v_lshl_add_u32 %[acc], %[acc], 1, %[t1]"
+                : [any] "+v"(any), [sum] "+v"(sumf), [acc] "+v"(a_h), [t0] "=&v"(t0), [t1] "=&v"(t1), [u0] "=&v"(u0), [u1] "=&v"(u1)
+                : [x0] "v"(pk[16 * h + k]), [x1] "v"(pk[16 * h + k - 1]), [ones] "s"(0x00010001u));
         }
+        acc[h] = a_h;
     }
     bad = (any & 0xC000C000u) != 0u;                                         // |a| > 16383 somewhere
     const unsigned nnz = (unsigned)__popc(acc[0]) + (unsigned)__popc(acc[1]);
-    const unsigned sum_bl = 64u * 31u - (unsigned)sumf;                        // sum of the bit lengths (zero: length 0)
+    const unsigned sum_bl = 33u * nnz - 64u - (unsigned)sumf;                  // sum of the bit lengths: sumf = sum over non-zeros of (32 - length) - zeros
     // the non-zero mask in coefficient order
     unsigned m[2];
 #pragma unroll
@@ -367,7 +387,8 @@ __device__ __forceinline__ unsigned rle_block_bytes(const unsigned (&pk)[32], bo
     }
     const unsigned bits = 8u + sum_bl + 9u * nnz + 8u * chains;
     // for the emitter's second lane: the bits of the codes of coefficients 0..31, and 1 + the last non-zero among them
-    const unsigned bits_lo = (32u * 31u - (unsigned)sumf_lo) + 9u * (unsigned)__popc(acc[0]) + 8u * chains_lo;
+    const unsigned nnz_lo = (unsigned)__popc(acc[0]);
+    const unsigned bits_lo = (33u * nnz_lo - 32u - (unsigned)sumf_lo) + 9u * nnz_lo + 8u * chains_lo;
     half = bits_lo | ((m[0] ? 32u - (unsigned)__clz((int)m[0]) : 0u) << 12);
     return (bits + 7u) >> 3;
 }
