@@ -397,8 +397,7 @@ __device__ __forceinline__ unsigned parse_tab(const unsigned *sw, const unsigned
                                               unsigned (&mark)[3])
 {
     unsigned n = 0, q = q0;
-    mark[0] = mark[1] = mark[2] = 0u;
-    for (int it = 1; __any(live); ++it) {
+    auto step = [&]() {
         const unsigned wi = q >> 5, sh = q & 31u;
         const unsigned d0 = sw[wi], d1 = sw[wi + 1], d2 = sw[wi + 2];
         const unsigned w = (unsigned)(((((unsigned long long)d0 << 32) | d1) << sh) >> 32);     // bits q .. q + 31
@@ -412,11 +411,17 @@ __device__ __forceinline__ unsigned parse_tab(const unsigned *sw, const unsigned
         live = go2 && n3 <= 64u;
         q += (go1 ? a1 : 0u) + (go2 ? a2 : 0u) + (live ? a3 : 0u);
         n = n3;
-        // way marks for the block decoder: where the walk stands after 15, 30 and 45 codes (bit offset into the block and
-        // coefficients so far), if it goes on from there -- four lanes can then share a block
-        if (it == MARK_STEPS || it == 2 * MARK_STEPS || it == 3 * MARK_STEPS)
-            mark[it / MARK_STEPS - 1] = live ? ((q - q0) << 8) | n : 0u;
+    };
+    // Way marks for the block decoder: where the walk stands after 15, 30 and 45 codes (bit offset into the block and
+    // coefficients so far), if it goes on from there -- four lanes can then share a block.  One loop per stretch between
+    // marks, so that no loop carries the marks through its iterations (as ONE loop with the marks assigned inside, every
+    // step paid six register moves for them).
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        for (int it = 0; it < MARK_STEPS && __ballot(live) != 0ull; ++it) step();
+        mark[k] = live ? ((q - q0) << 8) | n : 0u;
     }
+    while (__ballot(live) != 0ull) step();
     const unsigned wi = q >> 5;
     const unsigned w = (unsigned)(((((unsigned long long)sw[wi] << 32) | sw[wi + 1]) << (q & 31u)) >> 32);
     return ((w >> 24) == 0u && q + 8u <= end_bits) ? (q + 15u) >> 3 : NIL;   // an end marker (+ the zero padding) inside the stream
