@@ -170,36 +170,58 @@ int ensure_streams(DevicePool *pool, bool image)
     return JPEGX_OK;
 }
 
-// wide integers -> bytes, checking 0..255 on the way, split over a few host threads (a 4096^2 int64 band is
-// 128 MiB: one core needs ~13 ms for it, eight need ~2)
+// Wide integers -> bytes in the pinned staging area, checking 0..255 on the way, and up to the device -- in strips, each
+// uploaded as soon as it is narrowed: the threads walk the strips together (every thread its share of the rows of strip
+// k, then of strip k + 1), the calling thread waits for a strip's last share and enqueues its copy, so only the last
+// strip's copy is not hidden behind the narrowing of the next.  What the narrowing costs is reading the wide array:
+// 128 MiB for a 4096^2 int64 band, ~13 ms on one core (JPEGX_NARROW_THREADS, default 8).
 template <typename T>
-bool narrow_rows(const T *src, ptrdiff_t src_pitch, int H, int W, uint8_t *dst, ptrdiff_t dst_pitch)
+int narrow_and_upload(const T *src, ptrdiff_t src_pitch, int H, int W, uint8_t *stage, void *d_dst, hipStream_t st)
 {
     const unsigned hw = std::thread::hardware_concurrency();
-    const int nthreads = (int)(((size_t)H * W < (1u << 20)) ? 1 : (hw >= 8 ? 8 : (hw ? hw : 1)));
+    static const int want = [] { const char *e = getenv("JPEGX_NARROW_THREADS"); return e && *e ? atoi(e) : 8; }();      // 8 / 16 / 32: 1.26-1.57 / 1.38-1.99 / 1.33-1.94 ms per int64 band (starting the threads costs more than sixteen gain)
+    const int nthreads = ((size_t)H * W < (1u << 20)) ? 1 : ((int)hw >= want ? (want > 0 ? want : 1) : (hw ? (int)hw : 1));
+    const int nstrips = nthreads == 1 ? 1 : 8;
     std::atomic<bool> ok{true};
-    auto work = [&](int y0, int y1) {
+    std::vector<std::atomic<int>> done(nstrips);
+    for (auto &d : done) d.store(0, std::memory_order_relaxed);
+    auto rows_of = [&](int k) { return (int)((long long)H * k / nstrips); };
+    auto work = [&](int t) {
         bool good = true;
-        for (int y = y0; y < y1; ++y) {
-            const T *s = src + (size_t)y * src_pitch;
-            uint8_t *d = dst + (size_t)y * dst_pitch;
-            T seen = 0;
-            for (int x = 0; x < W; ++x) {
-                seen |= s[x];
-                d[x] = (uint8_t)s[x];
+        for (int k = 0; k < nstrips; ++k) {
+            const int r0 = rows_of(k), r1 = rows_of(k + 1);
+            const int y0 = r0 + (int)((long long)(r1 - r0) * t / nthreads), y1 = r0 + (int)((long long)(r1 - r0) * (t + 1) / nthreads);
+            for (int y = y0; y < y1; ++y) {
+                const T *sp = src + (size_t)y * src_pitch;
+                uint8_t *d = stage + (size_t)y * W;
+                T seen = 0;
+                for (int x = 0; x < W; ++x) {
+                    seen |= sp[x];
+                    d[x] = (uint8_t)sp[x];
+                }
+                if (seen & ~(T)0xFF) good = false;           // a negative value or one above 255 in this row
             }
-            if (seen & ~(T)0xFF) good = false;               // a negative value or one above 255 in this row
+            done[k].fetch_add(1, std::memory_order_release);
         }
         if (!good) ok = false;
     };
-    if (nthreads == 1) {
-        work(0, H);
-    } else {
-        std::vector<std::thread> th;
-        for (int t = 0; t < nthreads; ++t) th.emplace_back(work, (int)((long long)H * t / nthreads), (int)((long long)H * (t + 1) / nthreads));
-        for (auto &t : th) t.join();
+    std::vector<std::thread> th;
+    hipError_t e = hipSuccess;
+    if (nthreads == 1) work(0);                               // a small band: here and now
+    else for (int t = 0; t < nthreads; ++t) th.emplace_back(work, t);
+    for (int k = 0; k < nstrips; ++k) {                       // the calling thread: wait for the strip, enqueue its copy
+        while (done[k].load(std::memory_order_acquire) < nthreads) __builtin_ia32_pause();
+        const int r0 = rows_of(k), r1 = rows_of(k + 1);
+        if (e == hipSuccess && r1 > r0)
+            e = hipMemcpyAsync(static_cast<uint8_t *>(d_dst) + (size_t)r0 * W, stage + (size_t)r0 * W, (size_t)(r1 - r0) * W, hipMemcpyHostToDevice, st);
     }
-    return ok;
+    for (auto &t : th) t.join();
+    if (!ok) {
+        (void)hipStreamSynchronize(st);                       // the strips already on their way read the staging area: let them finish
+        return fail(JPEGX_E_UNSUPPORTED, "samples outside 0..255: not an 8-bit band");
+    }
+    if (e != hipSuccess) return fail(JPEGX_E_HIP, "host to device copy failed");
+    return JPEGX_OK;
 }
 
 // Touch every page of a (usually fresh) result buffer with a few host threads: the kernel hands out zeroed pages one
@@ -293,16 +315,17 @@ int enqueue_front(DevicePool *pool, BandSlot &slot, uint8_t *stage, const void *
     const uint8_t *src8 = static_cast<const uint8_t *>(h_plane);
     ptrdiff_t src_pitch = pitch;
     if (elem_size != 1) {
-        const bool ok = elem_size == 8 ? narrow_rows(static_cast<const int64_t *>(h_plane), pitch, HH, WW, stage, WW)
-                                       : narrow_rows(static_cast<const int32_t *>(h_plane), pitch, HH, WW, stage, WW);
-        if (!ok) return fail(JPEGX_E_UNSUPPORTED, "samples outside 0..255: not an 8-bit band");
-        src8 = stage;
-        src_pitch = WW;
+        // wide integers: narrowed into the pinned staging area strip by strip, every strip on its way to the device while
+        // the next is narrowed
+        rc = elem_size == 8 ? narrow_and_upload(static_cast<const int64_t *>(h_plane), pitch, HH, WW, stage, slot.d_in.p, st)
+                            : narrow_and_upload(static_cast<const int32_t *>(h_plane), pitch, HH, WW, stage, slot.d_in.p, st);
+        if (rc) return rc;
+    } else {
+        hipError_t e = (src_pitch == WW)
+            ? hipMemcpyAsync(slot.d_in.p, src8, in_bytes, hipMemcpyHostToDevice, st)
+            : hipMemcpy2DAsync(slot.d_in.p, WW, src8, (size_t)src_pitch, WW, HH, hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) return fail(JPEGX_E_HIP, "host to device copy failed");
     }
-    hipError_t e = (src_pitch == WW)
-        ? hipMemcpyAsync(slot.d_in.p, src8, in_bytes, hipMemcpyHostToDevice, st)
-        : hipMemcpy2DAsync(slot.d_in.p, WW, src8, (size_t)src_pitch, WW, HH, hipMemcpyHostToDevice, st);
-    if (e != hipSuccess) return fail(JPEGX_E_HIP, "host to device copy failed");
     if (fused_pool) {
         // the forward kernel sizes its blocks from the registers (RunLengthEncoding's bit counts): no second pass over the
         // stream, and the scan that follows writes the workspace's head itself -- two launches, no memset
@@ -653,7 +676,7 @@ int jpegx_host_decompress_plane_i64(const uint8_t *h_bytes, size_t nbytes, int H
     if ((rc = decompress_plane_locked(pool, h_bytes, nbytes, H, W, bs, mode, param, stage, pitch, false))) return rc;
     touch.wait();
     const unsigned hw = std::thread::hardware_concurrency();
-    static const int want = [] { const char *e = getenv("JPEGX_WIDEN_THREADS"); return e && *e ? atoi(e) : 8; }();      // A/B
+    static const int want = [] { const char *e = getenv("JPEGX_WIDEN_THREADS"); return e && *e ? atoi(e) : 8; }();      // A/B (8: 1.8-2.4 ms, 16: 1.7-2.6 ms per 4096^2 band: no difference)
     const int nthreads = ((size_t)rows * cols < (1u << 20)) ? 1 : ((int)hw >= want ? want : (hw ? (int)hw : 1));
     // non-temporal stores: the array is written once, 8 bytes per sample, and is eight times the size of what is read --
     // ordinary stores would first READ every line of it for ownership (twice the memory traffic)

@@ -404,3 +404,26 @@ def test_explicit_device_forms_of_the_entries(gpu):
     finally:
         L.jpegx_free_on(0, din)
         L.jpegx_free_on(0, dzz)
+
+
+@pytest.mark.parametrize("dtype", [np.int64, np.int32])
+def test_wide_integer_bands_are_narrowed_in_strips_and_uploaded_as_they_come(gpu, dtype):
+    """What util.band_to_array hands compress_band is an int64 array (util.py:110-112).  The native job narrows it to bytes
+    on host threads strip by strip, each strip on its way to the device while the next is narrowed (large bands only:
+    this one takes that path, the golden 64 x 64 cases do not): same bytes as the uint8 band, for heights that do not
+    divide into the strips and threads evenly; a sample outside 0..255 anywhere -- the last row included -- is not an
+    8-bit band, and the job hands it to the step-by-step path like the reference would run it."""
+    for h, w in ((2048, 2048), (1040, 1552), (4096, 272)):
+        band8 = gpu.synth.generate_plane("smooth", h, w, seed=h + w, dtype=np.int64).astype(np.uint8)
+        want = gpu.compress_plane_native(band8, 1, "qtable", 0.0)
+        wide = band8.astype(dtype)
+        assert gpu.compress_plane_native(wide, 1, "qtable", 0.0) == want, (h, w)
+        assert gpu.compress_plane_native(wide, 2, "qtable", 0.0) == gpu.compress_plane_native(band8, 2, "qtable", 0.0)
+        for y, x, v in ((h - 1, w - 1, 256), (0, 0, -1), (h // 2 + 3, 5, 1 << 20)):
+            bad = wide.copy()
+            bad[y, x] = v
+            assert gpu.compress_plane_native(bad, 1, "qtable", 0.0) is None, (h, w, y, x)
+        assert gpu.compress_plane_native(wide, 1, "qtable", 0.0) == want                    # and the pool is fine afterwards
+    cfg = Configuration(width=2048, height=2048, block_size=1, dct_size=8, quantization=QuantizationMethod("qtable"))
+    band8 = gpu.synth.generate_plane("noise", 2048, 2048, seed=3, dtype=np.int64).astype(np.uint8)
+    assert compress_band(band8.astype(np.int64), cfg) == compress_band(band8, cfg)
