@@ -18,6 +18,7 @@
 #include <sys/mman.h>
 
 #include <atomic>
+#include <functional>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -93,8 +94,11 @@ struct BandSlot {
     bool sized = false;           // compress: the forward kernel sized the blocks itself (half_info is there)
 };
 
+// One job context: a stream set and grow-only buffers.  A device has POOL_CONTEXTS of them, so that jobs of several host
+// threads overlap on the device (one's upload under another's kernels and download) instead of queueing behind one lock;
+// a single-threaded caller only ever meets the first (the others stay empty).
 struct DevicePool {
-    std::mutex mu;                // one host job at a time per device
+    std::mutex mu;                // one host job at a time per context
     hipStream_t stream = nullptr; // single-band jobs and the host-pointer conveniences
     hipStream_t aux[2] = {nullptr, nullptr};   // image jobs: bands alternate between these two
     hipEvent_t ev[MAX_BANDS] = {};
@@ -106,7 +110,8 @@ struct DevicePool {
     size_t out_bytes = 0;
 };
 
-DevicePool g_pool[MAX_DEVICES];
+constexpr int POOL_CONTEXTS = 4;
+DevicePool g_pool[MAX_DEVICES][POOL_CONTEXTS];
 
 // The pool this thread holds across C calls (an open compress job) or inside one (a borrowed working set).  Every
 // pooled entry asks here first: a thread that already holds the pool gets JPEGX_E_INVALID instead of locking the
@@ -115,27 +120,23 @@ DevicePool g_pool[MAX_DEVICES];
 thread_local DevicePool *t_held = nullptr;
 thread_local int t_held_device = -1;
 
-int current_pool(DevicePool **pool, int *device = nullptr)
+// lock a job context of the current device for this thread (released by unlock_pool): the first one that is free, or --
+// all busy -- the one this thread's id hashes to
+int lock_pool(DevicePool **out)
 {
     int dev = 0;
     HP_TRY(hipGetDevice(&dev));
     if (dev < 0 || dev >= MAX_DEVICES) return fail(JPEGX_E_UNSUPPORTED, "device index beyond the pool table");
-    *pool = &g_pool[dev];
-    if (device) *device = dev;
-    return JPEGX_OK;
-}
-
-// lock the current device's pool for this thread (released by unlock_pool)
-int lock_pool(DevicePool **out)
-{
-    DevicePool *pool = nullptr;
-    int dev = 0;
-    int rc = current_pool(&pool, &dev);
-    if (rc) return rc;
     if (t_held != nullptr)
         return fail(JPEGX_E_INVALID, t_held->open ? "a compress job is open on this thread: finish or abort it first"
                                                    : "this thread already holds a device pool");
-    pool->mu.lock();
+    DevicePool *pool = nullptr;
+    for (int k = 0; k < POOL_CONTEXTS && !pool; ++k)
+        if (g_pool[dev][k].mu.try_lock()) pool = &g_pool[dev][k];
+    if (!pool) {
+        pool = &g_pool[dev][std::hash<std::thread::id>()(std::this_thread::get_id()) % POOL_CONTEXTS];
+        pool->mu.lock();
+    }
     t_held = pool;
     t_held_device = dev;
     *out = pool;
@@ -839,17 +840,27 @@ void jpegx_internal_pool_release(void)
 // release everything the pools hold on the current device (tests; long-lived processes that are done)
 int jpegx_host_pool_release(void)
 {
-    PoolLock lock;
-    if (lock.rc) return lock.rc;
-    DevicePool *pool = lock.pool;
-    for (BandSlot &b : pool->slot)
-        for (Span *s : {&b.d_in, &b.d_zz, &b.d_ws, &b.d_out, &b.d_tmp}) s->release();
-    for (Span *s : {&pool->d_packed, &pool->h_in, &pool->h_out, &pool->h_head}) s->release();
-    if (pool->stream) { (void)hipStreamDestroy(pool->stream); pool->stream = nullptr; }
-    for (hipStream_t &s : pool->aux)
-        if (s) { (void)hipStreamDestroy(s); s = nullptr; }
-    for (hipEvent_t &e : pool->ev)
-        if (e) { (void)hipEventDestroy(e); e = nullptr; }
+    int dev = 0;
+    HP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= MAX_DEVICES) return fail(JPEGX_E_UNSUPPORTED, "device index beyond the pool table");
+    if (t_held != nullptr)
+        return fail(JPEGX_E_INVALID, t_held->open ? "a compress job is open on this thread: finish or abort it first"
+                                                   : "this thread already holds a device pool");
+    for (DevicePool &ctx : g_pool[dev]) {
+        std::lock_guard<std::mutex> guard(ctx.mu);           // waits for a job of another thread to finish
+        DevicePool *pool = &ctx;
+        for (BandSlot &b : pool->slot) {
+            for (Span *s : {&b.d_in, &b.d_zz, &b.d_ws, &b.d_out, &b.d_tmp, &b.d_seg, &b.d_seg_state}) s->release();
+            b.seg_clean = nullptr;
+            b.seg_clean_cap = 0;
+        }
+        for (Span *s : {&pool->d_packed, &pool->h_in, &pool->h_out, &pool->h_head}) s->release();
+        if (pool->stream) { (void)hipStreamDestroy(pool->stream); pool->stream = nullptr; }
+        for (hipStream_t &s : pool->aux)
+            if (s) { (void)hipStreamDestroy(s); s = nullptr; }
+        for (hipEvent_t &e : pool->ev)
+            if (e) { (void)hipEventDestroy(e); e = nullptr; }
+    }
     return JPEGX_OK;
 }
 

@@ -298,9 +298,11 @@ int jpegx_host_idct8x8_f32(const float *h_in, int H, int W, float *h_out);
  * util.band_to_array hands over (util.py:110-112); wide integers are range-checked (0..255, else
  * JPEGX_E_UNSUPPORTED) and narrowed by a few host threads.  _begin uploads, runs steps 1+4+5+6 (fused) and
  * 7+8 (device entropy stage) on the device's pooled stream and buffers, and reports the size of the byte
- * stream; _finish copies it into h_out (>= that many bytes).  Between the two calls the device's pool is
- * held by the calling thread (any other pooled entry -- a second _begin, the host conveniences, _decompress_*,
- * _pool_release -- returns JPEGX_E_INVALID on that thread until then; other threads wait); _finish / _abort act on
+ * stream; _finish copies it into h_out (>= that many bytes).  Between the two calls one of the device's job contexts
+ * (four per device: streams + grow-only buffers each, so that the jobs of several host threads overlap on the device)
+ * is held by the calling thread: any other pooled entry -- a second _begin, the host conveniences, _decompress_*,
+ * _pool_release -- returns JPEGX_E_INVALID on that thread until then; other threads take another context, or wait
+ * when all are busy; _finish / _abort act on
  * the job the thread opened, whatever its current device has become; _abort gives the pool back without copying.  bs 1, 2, 4: the uint8 kernels with
  * the mean folded in (W*bs a multiple of 16); any other bs: jpegx_mean_pool_f64 + jpegx_forward_fused_f64. */
 int jpegx_host_compress_begin(const void *h_plane, int elem_size, int H, int W, ptrdiff_t pitch, int bs,
@@ -346,7 +348,8 @@ int jpegx_interleave_u8(const void *const *d_planes, int nbands, int rows, int c
                         ptrdiff_t out_pitch, jpegx_stream_t stream);
 /* the entropy decoding alone on the device: bytes -> int16 [nblocks][64] (= jpegx_host_entropy_decode) */
 int jpegx_host_entropy_decode_gpu(const uint8_t *h_bytes, size_t nbytes, long long nblocks, int16_t *h_zz);
-/* frees the pooled device / pinned buffers and the pooled stream of the current device */
+/* frees the pooled device / pinned buffers and streams of every job context of the current device (waits for jobs
+ * of other threads to finish; JPEGX_E_INVALID while the calling thread itself holds a context) */
 int jpegx_host_pool_release(void);
 
 /* ---- explicit-device forms: jpegx_<name>_on(device, ...) == jpegx_<name>(...) with `device` made current for the

@@ -427,3 +427,34 @@ def test_wide_integer_bands_are_narrowed_in_strips_and_uploaded_as_they_come(gpu
     cfg = Configuration(width=2048, height=2048, block_size=1, dct_size=8, quantization=QuantizationMethod("qtable"))
     band8 = gpu.synth.generate_plane("noise", 2048, 2048, seed=3, dtype=np.int64).astype(np.uint8)
     assert compress_band(band8.astype(np.int64), cfg) == compress_band(band8, cfg)
+
+
+def test_concurrent_callers_share_a_device(gpu, golden):
+    """Several host threads in the band calls at once (ctypes drops the GIL): a device has four job contexts, every
+    context its own streams, buffers and decoder state, so the calls overlap instead of queueing behind one lock -- and
+    every one of them returns what it returns alone."""
+    import threading
+    cfg = Configuration(width=1024, height=1024, block_size=1, dct_size=8, quantization=QuantizationMethod("qtable"))
+    cfg2 = Configuration(width=1024, height=1024, block_size=2, dct_size=8, quantization=QuantizationMethod("divide", divisor=9))
+    bands = [gpu.synth.generate_plane(k, 1024, 1024, seed=s, dtype=np.int64).astype(np.uint8) for k in ("noise", "smooth") for s in (1, 2, 3)]
+    want = [(compress_band(b, cfg), compress_band(b, cfg2)) for b in bands]
+    back = [(pipeline.decompress_band_u8(w[0], cfg), pipeline.decompress_band_u8(w[1], cfg2)) for w in want]
+    errors = []
+
+    def worker(tid):
+        try:
+            for rep in range(12):
+                i = (tid + rep) % len(bands)
+                if compress_band(bands[i], cfg) != want[i][0] or compress_band(bands[i].astype(np.int64), cfg2) != want[i][1]:
+                    errors.append(("compress", tid, rep))
+                if not np.array_equal(pipeline.decompress_band_u8(want[i][0], cfg), back[i][0]) or \
+                        not np.array_equal(np.asarray(decompress_band(want[i][1], cfg2)), back[i][1]):
+                    errors.append(("decompress", tid, rep))
+        except Exception as exc:                                            # noqa: BLE001 -- reported below
+            errors.append((type(exc).__name__, str(exc)[:200], tid))
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(6)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:5]
