@@ -36,10 +36,21 @@ def main():
         cfg = pipeline.Configuration(width=size, height=size, block_size=1, dct_size=8,
                                      quantization=pipeline.QuantizationMethod("qtable"))
         blob = pipeline.compress_band(band, cfg)
-        for name, fn in (("compress_band", lambda: pipeline.compress_band(band, cfg)),
-                         ("decompress_band_u8", lambda: pipeline.decompress_band_u8(blob, cfg))):
+        back = pipeline.decompress_band_u8(blob, cfg)
+        bad = []
+
+        def checked_compress():
+            if pipeline.compress_band(band, cfg) != blob:
+                bad.append("compress")
+
+        def checked_decompress():
+            if not np.array_equal(pipeline.decompress_band_u8(blob, cfg), back):
+                bad.append("decompress")
+        for name, fn, checked in (("compress_band", lambda: pipeline.compress_band(band, cfg), checked_compress),
+                                  ("decompress_band_u8", lambda: pipeline.decompress_band_u8(blob, cfg), checked_decompress)):
             for n in (1, 2, 4, 8):
-                run(n, fn, 3)                                                   # every context grows to the working size
+                run(n, checked, 4)                                              # every context grows to the working size; results compared (untimed)
+                assert not bad, (kind, name, n, bad[:3])
                 rate = max(run(n, fn, 24) for _ in range(2))
                 print("%-6s %-19s %d caller thread%s: %7.0f bands/s  (%.2f ms per band and thread)"
                       % (kind, name, n, " " if n == 1 else "s", rate, n / rate * 1e3), flush=True)
