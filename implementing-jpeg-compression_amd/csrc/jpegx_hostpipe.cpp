@@ -102,6 +102,7 @@ struct DevicePool {
     hipStream_t stream = nullptr; // single-band jobs and the host-pointer conveniences
     hipStream_t aux[2] = {nullptr, nullptr};   // image jobs: bands alternate between these two
     hipEvent_t ev[MAX_BANDS] = {};
+    hipEvent_t ev_x = nullptr;    // image jobs from packed pixels: the planes are there
     BandSlot slot[MAX_BANDS];     // slot 0 doubles as the single-band working set
     Span d_packed;                // image jobs: the pixel-interleaved picture before it goes down
     Span h_in{nullptr, 0, true}, h_out{nullptr, 0, true}, h_head{nullptr, 0, true};
@@ -167,6 +168,7 @@ int ensure_streams(DevicePool *pool, bool image)
             if (!pool->aux[i]) HP_TRY(hipStreamCreateWithFlags(&pool->aux[i], hipStreamNonBlocking));
         for (int i = 0; i < MAX_BANDS; ++i)
             if (!pool->ev[i]) HP_TRY(hipEventCreateWithFlags(&pool->ev[i], hipEventDisableTiming));
+        if (!pool->ev_x) HP_TRY(hipEventCreateWithFlags(&pool->ev_x, hipEventDisableTiming));
     }
     return JPEGX_OK;
 }
@@ -315,7 +317,9 @@ int enqueue_front(DevicePool *pool, BandSlot &slot, uint8_t *stage, const void *
         return rc;
     const uint8_t *src8 = static_cast<const uint8_t *>(h_plane);
     ptrdiff_t src_pitch = pitch;
-    if (elem_size != 1) {
+    if (h_plane == nullptr) {
+        // the plane is in slot.d_in already (image jobs from packed pixels: de-interleaved on the device)
+    } else if (elem_size != 1) {
         // wide integers: narrowed into the pinned staging area strip by strip, every strip on its way to the device while
         // the next is narrowed
         rc = elem_size == 8 ? narrow_and_upload(static_cast<const int64_t *>(h_plane), pitch, HH, WW, stage, slot.d_in.p, st)
@@ -455,15 +459,21 @@ int jpegx_host_compress_abort(void)
 // destination's pages are touched by a few host threads (fresh memory: the kernel hands out zeroed pages one fault
 // at a time, which costs more than the copy itself) while the emit kernels run, then every band's bytes are
 // copied from the device straight to their place.
-int jpegx_host_compress_image(const void *const *h_planes, int nbands, int elem_size, int H, int W, ptrdiff_t pitch, int bs,
-                              int mode, double param, const void *prefix, size_t prefix_len, int length_prefixes,
-                              jpegx_alloc_fn alloc, void *user, size_t *nbytes)
+static int compress_image_impl(const void *const *h_planes, const uint8_t *h_packed, int nbands, int elem_size, int H, int W, ptrdiff_t pitch, int bs,
+                               int mode, double param, const void *prefix, size_t prefix_len, int length_prefixes,
+                               jpegx_alloc_fn alloc, void *user, size_t *nbytes)
 {
-    if (!h_planes || !alloc || !nbytes || (prefix_len && !prefix)) return fail(JPEGX_E_INVALID, "null pointer");
+    if ((!h_planes && !h_packed) || !alloc || !nbytes || (prefix_len && !prefix)) return fail(JPEGX_E_INVALID, "null pointer");
     if (nbands < 1 || nbands > MAX_BANDS) return fail(JPEGX_E_INVALID, "compress_image takes 1..JPEGX_MAX_IMAGE_BANDS bands");
     int rc;
-    for (int k = 0; k < nbands; ++k)
-        if ((rc = check_compress_shape(h_planes[k], elem_size, H, W, pitch, bs))) return rc;
+    if (h_packed) {
+        if ((rc = check_compress_shape(h_packed, 1, H, W, (ptrdiff_t)W * bs, bs))) return rc;
+        if (pitch < (ptrdiff_t)W * bs * nbands) return fail(JPEGX_E_INVALID, "packed pitch smaller than a row of pixels");
+        if ((long long)H * bs > 65535) return fail(JPEGX_E_UNSUPPORTED, "packed pixels: more than 65535 rows");
+    } else {
+        for (int k = 0; k < nbands; ++k)
+            if ((rc = check_compress_shape(h_planes[k], elem_size, H, W, pitch, bs))) return rc;
+    }
     PoolLock lock;
     if (lock.rc) return lock.rc;
     DevicePool *pool = lock.pool;
@@ -471,15 +481,37 @@ int jpegx_host_compress_image(const void *const *h_planes, int nbands, int elem_
     const size_t in_bytes = (size_t)H * bs * W * bs;
     const long long nblocks = (long long)(H / 8) * (W / 8);
     if ((rc = pool->h_head.ensure(16 * MAX_BANDS))) return rc;
-    if (elem_size != 1 && (rc = pool->h_in.ensure(in_bytes * nbands))) return rc;
+    if (!h_packed && elem_size != 1 && (rc = pool->h_in.ensure(in_bytes * nbands))) return rc;
     unsigned long long *heads = static_cast<unsigned long long *>(pool->h_head.p);
     auto drain = [&]() { (void)hipStreamSynchronize(pool->aux[0]); (void)hipStreamSynchronize(pool->aux[1]); };
     const Trace tr;
     tr.mark("compress_image: pool ready");
+    if (h_packed) {
+        // [rows][cols][nbands] pixels (what np.asarray(image) gives: half the host time of image.split() + one array per
+        // band): one upload, the planes made on the device, then the bands as below without their own uploads
+        const int rows = H * bs, cols = W * bs;
+        const size_t row_bytes = (size_t)cols * nbands;
+        if ((rc = pool->d_packed.ensure((size_t)rows * row_bytes))) return rc;
+        void *planes[MAX_BANDS] = {};
+        for (int k = 0; k < nbands; ++k) {
+            if ((rc = pool->slot[k].d_in.ensure(in_bytes))) return rc;
+            planes[k] = pool->slot[k].d_in.p;
+        }
+        hipError_t e = ((size_t)pitch == row_bytes)
+            ? hipMemcpyAsync(pool->d_packed.p, h_packed, (size_t)rows * row_bytes, hipMemcpyHostToDevice, pool->aux[0])
+            : hipMemcpy2DAsync(pool->d_packed.p, row_bytes, h_packed, (size_t)pitch, row_bytes, (size_t)rows, hipMemcpyHostToDevice, pool->aux[0]);
+        if (e != hipSuccess) { drain(); return fail(JPEGX_E_HIP, "host to device copy failed"); }
+        if ((rc = jpegx_deinterleave_u8(static_cast<const uint8_t *>(pool->d_packed.p), (ptrdiff_t)row_bytes, nbands, rows, cols, planes, cols, pool->aux[0]))) { drain(); return rc; }
+        if (hipEventRecord(pool->ev_x, pool->aux[0]) != hipSuccess || hipStreamWaitEvent(pool->aux[1], pool->ev_x, 0) != hipSuccess) {
+            drain();
+            return fail(JPEGX_E_HIP, "event between the image job's streams failed");
+        }
+        tr.mark("pixels enqueued");
+    }
     for (int k = 0; k < nbands; ++k) {
         hipStream_t st = pool->aux[k & 1];
-        uint8_t *stage = elem_size != 1 ? static_cast<uint8_t *>(pool->h_in.p) + in_bytes * k : nullptr;
-        rc = enqueue_front(pool, pool->slot[k], stage, h_planes[k], elem_size, H, W, pitch, bs, mode, param, st);
+        uint8_t *stage = (!h_packed && elem_size != 1) ? static_cast<uint8_t *>(pool->h_in.p) + in_bytes * k : nullptr;
+        rc = enqueue_front(pool, pool->slot[k], stage, h_packed ? nullptr : h_planes[k], h_packed ? 1 : elem_size, H, W, pitch, bs, mode, param, st);
         if (!rc && hipMemcpyAsync(heads + 2 * k, pool->slot[k].d_ws.p, 16, hipMemcpyDeviceToHost, st) != hipSuccess)
             rc = fail(JPEGX_E_HIP, "device to host copy failed");
         if (!rc && hipEventRecord(pool->ev[k], st) != hipSuccess) rc = fail(JPEGX_E_HIP, "hipEventRecord failed");
@@ -527,6 +559,23 @@ int jpegx_host_compress_image(const void *const *h_planes, int nbands, int elem_
     HP_TRY(hipStreamSynchronize(pool->aux[1]));
     tr.mark("compress_image: done");
     return JPEGX_OK;
+}
+
+int jpegx_host_compress_image(const void *const *h_planes, int nbands, int elem_size, int H, int W, ptrdiff_t pitch, int bs,
+                              int mode, double param, const void *prefix, size_t prefix_len, int length_prefixes,
+                              jpegx_alloc_fn alloc, void *user, size_t *nbytes)
+{
+    if (!h_planes) return fail(JPEGX_E_INVALID, "null pointer");
+    return compress_image_impl(h_planes, nullptr, nbands, elem_size, H, W, pitch, bs, mode, param, prefix, prefix_len, length_prefixes, alloc, user, nbytes);
+}
+
+// the same from pixel-interleaved samples, [H * bs][W * bs][nbands] uint8 with rows `pitch` bytes apart (np.asarray(image))
+int jpegx_host_compress_image_packed(const uint8_t *h_pixels, int nbands, int H, int W, ptrdiff_t pitch, int bs,
+                                     int mode, double param, const void *prefix, size_t prefix_len, int length_prefixes,
+                                     jpegx_alloc_fn alloc, void *user, size_t *nbytes)
+{
+    if (!h_pixels) return fail(JPEGX_E_INVALID, "null pointer");
+    return compress_image_impl(nullptr, h_pixels, nbands, 1, H, W, pitch, bs, mode, param, prefix, prefix_len, length_prefixes, alloc, user, nbytes);
 }
 
 }  // extern "C"
@@ -860,6 +909,7 @@ int jpegx_host_pool_release(void)
             if (s) { (void)hipStreamDestroy(s); s = nullptr; }
         for (hipEvent_t &e : pool->ev)
             if (e) { (void)hipEventDestroy(e); e = nullptr; }
+        if (pool->ev_x) { (void)hipEventDestroy(pool->ev_x); pool->ev_x = nullptr; }
     }
     return JPEGX_OK;
 }

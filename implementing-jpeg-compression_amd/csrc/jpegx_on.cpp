@@ -66,6 +66,8 @@ JPEGX_ON(jpegx_host_compress_begin, (int device, const void *h_plane, int elem_s
          (h_plane, elem_size, H, W, pitch, bs, mode, param, nbytes))
 JPEGX_ON(jpegx_host_compress_image, (int device, const void *const *h_planes, int nbands, int elem_size, int H, int W, ptrdiff_t pitch, int bs, int mode, double param, const void *prefix, size_t prefix_len, int length_prefixes, jpegx_alloc_fn alloc, void *user, size_t *nbytes),
          (h_planes, nbands, elem_size, H, W, pitch, bs, mode, param, prefix, prefix_len, length_prefixes, alloc, user, nbytes))
+JPEGX_ON(jpegx_host_compress_image_packed, (int device, const uint8_t *h_pixels, int nbands, int H, int W, ptrdiff_t pitch, int bs, int mode, double param, const void *prefix, size_t prefix_len, int length_prefixes, jpegx_alloc_fn alloc, void *user, size_t *nbytes),
+         (h_pixels, nbands, H, W, pitch, bs, mode, param, prefix, prefix_len, length_prefixes, alloc, user, nbytes))
 JPEGX_ON(jpegx_host_decompress_plane, (int device, const uint8_t *h_bytes, size_t nbytes, int H, int W, int bs, int mode, double param, uint8_t *h_out, ptrdiff_t out_pitch),
          (h_bytes, nbytes, H, W, bs, mode, param, h_out, out_pitch))
 JPEGX_ON(jpegx_host_decompress_plane_i64, (int device, const uint8_t *h_bytes, size_t nbytes, int H, int W, int bs, int mode, double param, int64_t *h_out, int rows, int cols),

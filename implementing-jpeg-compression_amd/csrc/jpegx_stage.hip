@@ -165,9 +165,56 @@ __global__ __launch_bounds__(256) void k_interleave_u8(InterleaveArgs a, int nb,
         for (int k = 0; k < nb; ++k) o[i * nb + k] = (unsigned char)(w[k] >> (8 * i));
 }
 
+// The way in (Jpeg.compress, pipeline/__init__.py:102-106: `image.split()`): [rows][cols][nb] packed pixels -> nb planes.
+// A thread takes four pixels: 4 nb bytes in (three dwords when nb = 3 and the row keeps them aligned), one dword per plane out.
+struct DeinterleaveArgs { unsigned char *plane[JPEGX_MAX_IMAGE_BANDS]; };
+
+__global__ __launch_bounds__(256) void k_deinterleave_u8(const unsigned char *__restrict__ in, size_t in_pitch, int nb, int rows, int cols,
+                                                         DeinterleaveArgs a, size_t pitch)
+{
+    const int x4 = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    const int x = x4 * 4;
+    if (x >= cols || y >= rows) return;
+    const unsigned char *p = in + (size_t)y * in_pitch + (size_t)x * nb;
+    const int npx = min(4, cols - x);
+    unsigned w[JPEGX_MAX_IMAGE_BANDS] = {};
+    if (nb == 3 && npx == 4 && (in_pitch & 3) == 0 && (reinterpret_cast<uintptr_t>(in) & 3u) == 0) {
+        const unsigned *p4 = reinterpret_cast<const unsigned *>(p);
+        const unsigned d0 = p4[0], d1 = p4[1], d2 = p4[2];       // bytes: a0 b0 c0 a1 | b1 c1 a2 b2 | c2 a3 b3 c3
+        w[0] = (d0 & 0xFFu) | ((d0 >> 24) << 8) | (((d1 >> 16) & 0xFFu) << 16) | (((d2 >> 8) & 0xFFu) << 24);
+        w[1] = ((d0 >> 8) & 0xFFu) | ((d1 & 0xFFu) << 8) | ((d1 >> 24) << 16) | (((d2 >> 16) & 0xFFu) << 24);
+        w[2] = ((d0 >> 16) & 0xFFu) | (((d1 >> 8) & 0xFFu) << 8) | ((d2 & 0xFFu) << 16) | ((d2 >> 24) << 24);
+    } else {
+        for (int i = 0; i < npx; ++i)
+            for (int k = 0; k < nb; ++k) w[k] |= (unsigned)p[i * nb + k] << (8 * i);
+    }
+#pragma unroll
+    for (int k = 0; k < JPEGX_MAX_IMAGE_BANDS; ++k)
+        if (k < nb) *reinterpret_cast<unsigned *>(a.plane[k] + (size_t)y * pitch + x) = w[k];      // pitch is a multiple of 4 covering the row rounded up to 4
+}
+
 }  // namespace
 
 extern "C" {
+
+int jpegx_deinterleave_u8(const uint8_t *d_in, ptrdiff_t in_pitch, int nbands, int rows, int cols, void *const *d_planes, ptrdiff_t pitch,
+                          jpegx_stream_t stream)
+{
+    if (!d_planes || !d_in) return fail(JPEGX_E_INVALID, "null device pointer");
+    if (nbands < 1 || nbands > JPEGX_MAX_IMAGE_BANDS || rows <= 0 || cols <= 0 || rows > 65535)
+        return fail(JPEGX_E_INVALID, "deinterleave: 1..JPEGX_MAX_IMAGE_BANDS planes, 1..65535 rows");
+    if ((pitch % 4) != 0 || pitch < ((cols + 3) & ~3) || in_pitch < (ptrdiff_t)cols * nbands)
+        return fail(JPEGX_E_INVALID, "deinterleave: plane pitch must be a multiple of 4 covering the row rounded up to 4; packed pitch >= cols * nbands");
+    DeinterleaveArgs a;
+    for (int k = 0; k < JPEGX_MAX_IMAGE_BANDS; ++k) {
+        a.plane[k] = k < nbands ? static_cast<unsigned char *>(d_planes[k]) : nullptr;
+        if (k < nbands && (!d_planes[k] || (reinterpret_cast<uintptr_t>(d_planes[k]) & 3u))) return fail(JPEGX_E_INVALID, "deinterleave: planes must be 4-byte aligned");
+    }
+    const dim3 block(256), grid(((cols + 3) / 4 + 255) / 256, rows);
+    hipLaunchKernelGGL(k_deinterleave_u8, grid, block, 0, (hipStream_t)stream, d_in, (size_t)in_pitch, nbands, rows, cols, a, (size_t)pitch);
+    HIP_TRY(hipGetLastError());
+    return JPEGX_OK;
+}
 
 int jpegx_interleave_u8(const void *const *d_planes, int nbands, int rows, int cols, ptrdiff_t pitch, uint8_t *d_out,
                         ptrdiff_t out_pitch, jpegx_stream_t stream)

@@ -123,7 +123,9 @@ SIGNATURES = {
     "jpegx_host_entropy_decode_gpu": [_vp, _sz, _c.c_longlong, _vp],
     "jpegx_host_compress_image": [_vp, _int, _int, _int, _int, _pd, _int, _int, _dbl, _vp, _sz, _int, _vp, _vp, _c.POINTER(_sz)],
     "jpegx_host_decompress_image": [_vp, _c.POINTER(_sz), _int, _int, _int, _int, _int, _dbl, _vp, _pd, _int, _int, _int],
+    "jpegx_host_compress_image_packed": [_vp, _int, _int, _int, _pd, _int, _int, _dbl, _vp, _sz, _int, _vp, _vp, _c.POINTER(_sz)],
     "jpegx_interleave_u8": [_vp, _int, _int, _int, _pd, _vp, _pd, _vp],
+    "jpegx_deinterleave_u8": [_vp, _pd, _int, _int, _int, _vp, _pd, _vp],
     "jpegx_entropy_workspace_bytes": [_c.c_longlong],
     "jpegx_entropy_sizes": [_vp, _c.c_longlong, _vp, _vp],
     "jpegx_entropy_total": [_vp, _c.POINTER(_c.c_ulonglong), _vp],
@@ -144,7 +146,7 @@ SIGNATURES = {
 for _name in ("jpegx_malloc", "jpegx_free", "jpegx_stream_create", "jpegx_generate_plane", "jpegx_forward_fused_pooled",
               "jpegx_forward_fused_u8", "jpegx_forward_fused_f64", "jpegx_forward_fused_planes", "jpegx_mean_pool_f64",
               "jpegx_inverse_fused_u8_inflated", "jpegx_entropy_sizes", "jpegx_entropy_total", "jpegx_entropy_block_sizes",
-              "jpegx_entropy_emit", "jpegx_host_compress_begin", "jpegx_host_compress_image", "jpegx_host_decompress_plane",
+              "jpegx_entropy_emit", "jpegx_host_compress_begin", "jpegx_host_compress_image", "jpegx_host_compress_image_packed", "jpegx_host_decompress_plane",
               "jpegx_host_decompress_plane_i64", "jpegx_host_decompress_image", "jpegx_host_entropy_decode_gpu",
               "jpegx_host_pool_release", "jpegx_comm_create_deadline"):
     SIGNATURES[_name + "_on"] = [_int] + SIGNATURES[_name]
@@ -679,6 +681,43 @@ def compress_image_native(planes, block_size=1, mode="qtable", param=0.0, prefix
     if rc == -4:                                        # JPEGX_E_UNSUPPORTED: not 8-bit bands after all
         return None
     check(rc, "jpegx_host_compress_image")
+    whole = box[0]
+    if prefix is not None:
+        return whole
+    out, at = [], 0
+    for n in sizes:
+        out.append(whole[at:at + n])
+        at += n
+    return out
+
+
+def compress_image_packed(pixels, block_size=1, mode="qtable", param=0.0, prefix=None):
+    """compress_image_native from pixel-interleaved samples: ``pixels`` is the (rows, cols, nbands) uint8 array that
+    np.asarray(image) gives for a multi-band PIL image -- half the host time of image.split() plus an array per band; the
+    planes are made on the device (jpegx_host_compress_image_packed).  rows and cols must be multiples of 8 * block_size
+    (no padding step in between).  Same bytes as compress_image_native; None when this road does not apply."""
+    a = pixels if isinstance(pixels, np.ndarray) else np.asarray(pixels)
+    bs = int(block_size)
+    if a.ndim != 3 or a.dtype != np.uint8 or not 1 <= a.shape[2] <= 4 or not a.flags.c_contiguous:
+        return None
+    hh, ww, nb = a.shape
+    if hh == 0 or hh % (8 * bs) or ww % (8 * bs) or not 1 <= bs <= 255 or hh > 65535:
+        return None
+    if bs in (1, 2, 4) and (ww % 16 or not u8_path_ok(ww // bs, bs, ww, mode, param)):
+        return None
+    L = lib()
+    box = []
+
+    def alloc(_user, nbytes):
+        blob = _pyapi.PyBytes_FromStringAndSize(None, nbytes)       # uninitialised bytes, filled by the device copies
+        box.append(blob)
+        return _pyapi.PyBytes_AsString(blob)
+    cb = ALLOC_FN(alloc)
+    sizes = (ctypes.c_size_t * nb)()
+    head = bytes(prefix) if prefix is not None else b""
+    check(L.jpegx_host_compress_image_packed(a.ctypes.data, nb, hh // bs, ww // bs, ww * nb, bs, mode_of(mode), float(param),
+                                             head, len(head), 1 if prefix is not None else 0, cb, None, sizes),
+          "jpegx_host_compress_image_packed")
     whole = box[0]
     if prefix is not None:
         return whole

@@ -343,6 +343,15 @@ int jpegx_host_compress_image(const void *const *h_planes, int nbands, int elem_
 int jpegx_host_decompress_image(const uint8_t *const *h_bytes, const size_t *nbytes, int nbands, int H, int W, int bs,
                                 int mode, double param, uint8_t *h_out, ptrdiff_t out_pitch, int rows, int cols,
                                 int interleave);
+/* compress_image from pixel-interleaved samples, [H*bs][W*bs][nbands] uint8, rows `pitch` bytes apart -- what
+ * np.asarray(image) hands over in half the host time of `image.split()` (pipeline/__init__.py:104) plus one array per
+ * band: one upload, the planes are made on the device (jpegx_deinterleave_u8), then as above.  Same bytes out. */
+int jpegx_host_compress_image_packed(const uint8_t *h_pixels, int nbands, int H, int W, ptrdiff_t pitch, int bs,
+                                     int mode, double param, const void *prefix, size_t prefix_len,
+                                     int length_prefixes, jpegx_alloc_fn alloc, void *user, size_t *nbytes);
+/* pixel-interleaved [rows][cols][nbands] (rows in_pitch bytes apart) -> device planes [rows][pitch] (uint8, pitch a multiple of 4) */
+int jpegx_deinterleave_u8(const uint8_t *d_in, ptrdiff_t in_pitch, int nbands, int rows, int cols, void *const *d_planes,
+                          ptrdiff_t pitch, jpegx_stream_t stream);
 /* device planes [rows][pitch] (uint8, pitch a multiple of 4) -> pixel-interleaved [rows][cols][nbands] */
 int jpegx_interleave_u8(const void *const *d_planes, int nbands, int rows, int cols, ptrdiff_t pitch, uint8_t *d_out,
                         ptrdiff_t out_pitch, jpegx_stream_t stream);
@@ -385,6 +394,9 @@ int jpegx_host_compress_begin_on(int device, const void *h_plane, int elem_size,
 int jpegx_host_compress_image_on(int device, const void *const *h_planes, int nbands, int elem_size, int H, int W,
                                  ptrdiff_t pitch, int bs, int mode, double param, const void *prefix, size_t prefix_len,
                                  int length_prefixes, jpegx_alloc_fn alloc, void *user, size_t *nbytes);
+int jpegx_host_compress_image_packed_on(int device, const uint8_t *h_pixels, int nbands, int H, int W, ptrdiff_t pitch, int bs,
+                                        int mode, double param, const void *prefix, size_t prefix_len, int length_prefixes,
+                                        jpegx_alloc_fn alloc, void *user, size_t *nbytes);
 int jpegx_host_decompress_plane_on(int device, const uint8_t *h_bytes, size_t nbytes, int H, int W, int bs, int mode,
                                    double param, uint8_t *h_out, ptrdiff_t out_pitch);
 int jpegx_host_decompress_plane_i64_on(int device, const uint8_t *h_bytes, size_t nbytes, int H, int W, int bs, int mode,

@@ -105,8 +105,35 @@ def image():
                   % (kind, bs, t1 * 1e3, t3s * 1e3, t3c * 1e3, t3 * 1e3, t3 / t1, up, down, d1 * 1e3, d3s * 1e3, d3 * 1e3, d3 / d1), flush=True)
 
 
+def jpeg_api():
+    """The reference's top-level calls on a 4096 x 4096 YCbCr picture: Jpeg.compress(image) -> container bytes ->
+    Jpeg.decompress -> image, with what PIL itself costs beside them."""
+    from PIL import Image
+    jpegx.require_device()
+    size = 4096
+    for kind in ("smooth", "noise"):
+        px = np.stack([jpegx.synth.generate_plane(kind, size, size, seed=s, dtype=np.int64).astype(np.uint8) for s in (1, 2, 3)], axis=-1)
+        im = Image.fromarray(px, mode="YCbCr")
+        for bs in (1, 2):
+            cfg = pipeline.Configuration(width=size, height=size, block_size=bs, dct_size=8,
+                                         quantization=pipeline.QuantizationMethod("qtable"))
+            codec = pipeline.Jpeg(cfg)
+            data = codec.compress(im)
+            pipeline.Jpeg.decompress(data)
+            tc, data = best(lambda: codec.compress(im), 5)
+            td, _ = best(lambda: pipeline.Jpeg.decompress(data), 5)
+            t_split, _ = best(lambda: [np.asarray(b) for b in im.split()], 3)
+            t_arr, _ = best(lambda: np.asarray(im), 3)
+            t_from, _ = best(lambda: Image.fromarray(px, mode="YCbCr"), 3)
+            print("%-6s block_size %d: Jpeg.compress %.1f ms (np.asarray(image) alone %.1f ms; image.split() + one array per band %.1f ms), "
+                  "Jpeg.decompress %.1f ms (Image.fromarray alone %.1f ms), container %d bytes"
+                  % (kind, bs, tc * 1e3, t_arr * 1e3, t_split * 1e3, td * 1e3, t_from * 1e3, len(data)), flush=True)
+
+
 if __name__ == "__main__":
-    if "--image" in sys.argv:
+    if "--jpeg" in sys.argv:
+        jpeg_api()
+    elif "--image" in sys.argv:
         image()
     else:
         main()

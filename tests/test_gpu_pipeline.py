@@ -321,6 +321,10 @@ def test_whole_image_job_equals_three_band_jobs(gpu, bs):
         per_band = [compress_band(np.asarray(b), cfg) for b in im.split()]
         blobs = gpu.compress_image_native([np.ascontiguousarray(np.asarray(b)) for b in im.split()], bs, *cfg.quantization.gpu_mode())
         assert blobs == per_band
+        # the same from the interleaved pixels in one piece (what Jpeg.compress hands over since round 3: no image.split())
+        assert gpu.compress_image_packed(np.asarray(im), bs, *cfg.quantization.gpu_mode()) == per_band
+        four = np.concatenate([np.asarray(im), 255 - np.asarray(im)[..., :1]], axis=-1)
+        assert gpu.compress_image_packed(np.ascontiguousarray(four), bs, *cfg.quantization.gpu_mode())[:3] == per_band
         data = pipeline.Jpeg(cfg).compress(im)
         assert data == file_format.generate_data(cfg, pipeline.CompressedData(*per_band))
         back = pipeline.Jpeg.decompress(data)
