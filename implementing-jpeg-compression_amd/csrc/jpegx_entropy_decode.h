@@ -23,10 +23,12 @@ struct SegPlan {
     unsigned nseg;
     size_t ws_bytes, state_bytes;   // scratch; the persistent state (status blocks + exit words)
     bool ok;                    // false: stream too long for this scheme
+    bool filter;                // first try: only candidates whose first byte can start a block
 };
 // level 0: segments sized from the stream's average block length; level 1: the smallest segments (256 bytes), the second try
 // for a stream whose local density overflowed a segment's tables (flat regions in a busy picture)
-SegPlan seg_plan(size_t nbytes, long long nblocks, int level = 0);
+// filter: 0 = keep every candidate also in the first try (a caller that has just seen the filter miss), -1 = the default
+SegPlan seg_plan(size_t nbytes, long long nblocks, int level = 0, int filter = -1);
 // d_state: state_cap >= plan.state_bytes bytes that only this scheme touches -- fresh: never used before (it is cleared whole, once;
 // afterwards every call leaves it clean); parity alternates from call to call on one d_state (the call's status words are at
 // d_state + 64 * parity).  d_ws: plan.ws_bytes of scratch.

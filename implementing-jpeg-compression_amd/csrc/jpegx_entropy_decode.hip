@@ -506,7 +506,7 @@ __device__ __forceinline__ void stage_pieces(const unsigned char *__restrict__ b
 }
 
 __global__ __launch_bounds__(64) void k_seg_starts(const unsigned char *__restrict__ bytes, size_t nbytes, int seg, int cmax, unsigned nseg,
-                                                   void *state, void *ws, long long nblocks, int parity)
+                                                   void *state, void *ws, long long nblocks, int parity, int filter)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
     const Ws W = carve(state, ws, nseg, cmax, nblocks, parity);
@@ -556,11 +556,14 @@ __global__ __launch_bounds__(64) void k_seg_starts(const unsigned char *__restri
     unsigned long long m;
     {
         const unsigned *swl = reinterpret_cast<const unsigned *>(sm + FRONT + p0);
-        unsigned long long z = 0;                                              // bit j: byte p0 + j is zero
+        unsigned long long z = 0, lk = 0;                                      // bit j: byte p0 + j is zero / has a zero high nibble
         for (int k = 0; k < (stretch >> 2); ++k) {
             const unsigned x = swl[k];
             const unsigned t = (~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu)) >> 7;   // bits 24, 16, 8, 0 <-> bytes 0..3
             z |= (unsigned long long)(((t * 0x08040201u) >> 24) & 15u) << (4 * k);
+            const unsigned y = x & 0xF0F0F0F0u;
+            const unsigned t2 = (~(((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y | 0x7F7F7F7Fu)) >> 7;
+            lk |= (unsigned long long)(((t2 * 0x08040201u) >> 24) & 15u) << (4 * k);
         }
         const unsigned top = (unsigned)(z >> (stretch - 1)) & 1u;
         const unsigned up = (unsigned)__shfl_up((int)top, 1);
@@ -569,6 +572,18 @@ __global__ __launch_bounds__(64) void k_seg_starts(const unsigned char *__restri
         const long long left = (long long)nbytes - (long long)base - p0;       // positions of this lane inside the stream
         const int nvalid = left <= 0 ? 0 : (left >= stretch ? stretch : (int)left);
         m &= nvalid >= 64 ? ~0ull : ((1ull << nvalid) - 1ull);
+        if (filter) {
+            // First try only: a block of this codec that holds anything starts with a header whose run nibble is zero
+            // (samples are non-negative: a non-zero coefficient means a non-zero DC), an empty one is the byte 0x00 -- so a
+            // true start has a first byte below 0x10, and most false candidates (a zero byte inside a block's bits) do
+            // not.  Dropping the others halves the candidates of a busy stream; positions up to REACH stay all (the chain
+            // from the segment in front may enter at any of them).  A chain that lands on a dropped position reads as a
+            // chain that leaves the candidates: with the filter on that hands the stream to the second try (all
+            // candidates, 256-byte segments), it does not refuse it.
+            const int nkeep = (int)REACH + 1 - p0;
+            const unsigned long long keep = nkeep <= 0 ? 0ull : (nkeep >= 64 ? ~0ull : ((1ull << nkeep) - 1ull));
+            m &= lk | keep;
+        }
     }
     const unsigned mine = (unsigned)__popcll(m);
     unsigned incl = mine;
@@ -716,7 +731,7 @@ __global__ __launch_bounds__(64) void k_seg_starts(const unsigned char *__restri
     JPEGX_PHASE(4);
     if (!poisoned) {
         if (entry == AFTER) myexit = AFTER;
-        else if (entry == INVALID) err |= 2u;
+        else if (entry == INVALID) err |= filter ? 0x100u : 2u;
         else {
             if (entry < 64u && entry < nent) {                                 // chased already, by lane `entry`
                 myexit = (unsigned)__shfl((int)my_exit_if_entry, (int)entry);
@@ -724,9 +739,10 @@ __global__ __launch_bounds__(64) void k_seg_starts(const unsigned char *__restri
             } else {
                 myexit = chase(entry, count);
             }
-            if (myexit == INVALID) { err |= 2u; count = 0; }
+            if (myexit == INVALID) { err |= filter ? 0x100u : 2u; count = 0; }
         }
-        if (err && lane == 0) __hip_atomic_fetch_or(ghead + 1, err, JPEGX_RLX_AGENT);
+        if ((err & 0xFFu) && lane == 0) __hip_atomic_fetch_or(ghead + 1, err & 0xFFu, JPEGX_RLX_AGENT);
+        if ((err & 0x100u) && lane == 0) __hip_atomic_fetch_or(ghead + 2, 4u, JPEGX_RLX_AGENT);      // filtered candidates: the next try decides
         // block r of the segment is the candidate r steps from the entry: its byte position and its way marks (held by
         // the lane that parsed it)
         for (unsigned r0 = 0; r0 < count; r0 += 64) {
@@ -941,7 +957,7 @@ int levels_for(long long nblocks)          // base-4 digits of the largest block
 }
 
 // ---- segmented scheme (round 3) ----------------------------------------------------------------------------------
-SegPlan seg_plan(size_t nbytes, long long nblocks, int level)
+SegPlan seg_plan(size_t nbytes, long long nblocks, int level, int filter)
 {
     SegPlan p;
     // One wave per segment and one parse per candidate: the segment should hold about 46 candidates, so that a 65th
@@ -950,7 +966,11 @@ SegPlan seg_plan(size_t nbytes, long long nblocks, int level)
     // in 150 (smooth, 28 bytes per block) is such a zero -- far more than the 1/256 of random bytes, because a run of 0
     // makes the header's high nibble zero.  Segments are multiples of 256 bytes (4 bytes per lane), 256 bytes to 4 KiB.
     const double per_block = (double)(nbytes ? nbytes : 1) / (double)(nblocks > 0 ? nblocks : 1);
-    const double per_byte = 1.0 / per_block + 1.0 / 90.0;
+    // first try: candidates whose first byte cannot start a block are dropped (k_seg_starts) -- what is left of the false
+    // ones is about one byte in 900 (measured on noise), against one in 81-150 without the filter
+    const char *nfl = getenv("JPEGX_DECODE_NOFILTER");
+    p.filter = level == 0 && filter != 0 && !(nfl && *nfl && *nfl != '0');
+    const double per_byte = 1.0 / per_block + (p.filter ? 1.0 / 900.0 : 1.0 / 90.0);
     int k = (int)(46.0 / per_byte / 256.0 + 0.5);
     const char *force = getenv("JPEGX_DECODE_SEG");                          // A/B runs
     if (force && *force) k = atoi(force) / 256;
@@ -988,7 +1008,7 @@ void enqueue_segmented(const uint8_t *d_bytes, size_t nbytes, long long nblocks,
 #endif
     const unsigned run8 = 8u << seg::RUN_LOG;                // the grid covers whole rounds of the XCDs' turns; the surplus returns at once
     hipLaunchKernelGGL(seg::k_seg_starts, dim3((p.nseg + run8 - 1) / run8 * run8), dim3(64), seg::lds_bytes(p.seg, p.cmax), st, d_bytes, nbytes, p.seg, p.cmax,
-                       p.nseg, d_state, d_ws, nblocks, parity);
+                       p.nseg, d_state, d_ws, nblocks, parity, p.filter ? 1 : 0);
     hipLaunchKernelGGL(seg::k_seg_scan, dim3(1), dim3(1024), 0, st, p.nseg, p.cmax, d_state, d_ws, nblocks, parity);
     hipLaunchKernelGGL(seg::k_dec_blocks_lds, dim3((unsigned)((nblocks + 63) / 64)), dim3(256), seg::dec_lds_bytes(p.span_cap), st, d_bytes, nbytes,
                        p.nseg, p.cmax, d_state, d_ws, (int)nblocks, p.span_cap, d_zz, parity);

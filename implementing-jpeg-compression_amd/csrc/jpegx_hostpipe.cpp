@@ -92,6 +92,11 @@ struct BandSlot {
     unsigned seg_calls = 0;
     int seg_parity = -1;          // status block of the last decode (-1: the general scheme ran, status in d_ws)
     bool sized = false;           // compress: the forward kernel sized the blocks itself (half_info is there)
+    // decoder, first try: candidates that cannot start a block of non-negative samples are dropped (jpegx_entropy_decode.hip).
+    // A stream with blocks that do start otherwise (DC 0 beside non-zero AC: very dark content) misses there and takes the
+    // second try; the filter then stays off for this working set's next calls, so that such content pays once in a while
+    unsigned filter_pause = 0;
+    bool last_filter = false;
 };
 
 // One job context: a stream set and grow-only buffers.  A device has POOL_CONTEXTS of them, so that jobs of several host
@@ -597,7 +602,9 @@ int decode_on_device(BandSlot &slot, size_t nbytes, long long nblocks, hipStream
     const char *force = getenv("JPEGX_DECODE_GENERAL");    // tests / A-B runs: the general scheme from the start
     if (force && *force && *force != '0') level = 2;
     if (level == 1 && jpegx_decode::seg_plan(nbytes, nblocks, 0).seg == 256) level = 2;      // the first try had the smallest segments already
-    const jpegx_decode::SegPlan plan = jpegx_decode::seg_plan(nbytes, nblocks, level);
+    const jpegx_decode::SegPlan plan = jpegx_decode::seg_plan(nbytes, nblocks, level, (level == 0 && slot.filter_pause > 0) ? 0 : -1);
+    if (level == 0 && slot.filter_pause > 0) --slot.filter_pause;
+    slot.last_filter = plan.filter;
     t_last_decode_level = level;
     if (level < 2 && plan.ok) {
         if ((rc = slot.d_seg.ensure(plan.ws_bytes)) || (rc = slot.d_seg_state.ensure(plan.state_bytes))) return rc;
@@ -640,7 +647,10 @@ int decode_status(BandSlot &slot)
             if (FILE *f = fopen(dump, "wb")) { fwrite(raw.data(), 1, raw.size(), f); fclose(f); }
         }
     }
-    if (seg && head[2] != 0) return DECODE_RETRY_GENERAL;
+    if (seg && head[2] != 0) {
+        if ((head[2] & 4u) && slot.last_filter) slot.filter_pause = 64;      // the candidate filter missed a block start: without it for a while
+        return DECODE_RETRY_GENERAL;
+    }
     if (head[1] != 0) return fail(JPEGX_E_INVALID, "entropy stream is not a sequence of well-formed blocks (device decoder)");
     return JPEGX_OK;
 }
@@ -902,6 +912,8 @@ int jpegx_host_pool_release(void)
             for (Span *s : {&b.d_in, &b.d_zz, &b.d_ws, &b.d_out, &b.d_tmp, &b.d_seg, &b.d_seg_state}) s->release();
             b.seg_clean = nullptr;
             b.seg_clean_cap = 0;
+            b.filter_pause = 0;
+            b.last_filter = false;
         }
         for (Span *s : {&pool->d_packed, &pool->h_in, &pool->h_out, &pool->h_head}) s->release();
         if (pool->stream) { (void)hipStreamDestroy(pool->stream); pool->stream = nullptr; }

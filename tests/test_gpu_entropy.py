@@ -161,6 +161,7 @@ def test_flat_regions_in_a_busy_stream_take_the_second_try_not_the_whole_stream_
     host round trip); single-byte blocks (all coefficients zero) overflow those too."""
     rng = np.random.default_rng(21)
     busy = rng.integers(-300, 300, (3000, 64)).astype(np.int16)
+    busy[:, 0] = rng.integers(1, 1000, 3000)                    # like every block of non-negative samples that holds anything: DC > 0
     flat = np.zeros((2500, 64), np.int16)
     flat[:, 0] = rng.integers(100, 1000, 2500)
     z = np.concatenate([busy[:1500], flat, busy[1500:]])
@@ -172,6 +173,40 @@ def test_flat_regions_in_a_busy_stream_take_the_second_try_not_the_whole_stream_
     black = np.concatenate([busy[:1500], np.zeros((4000, 64), np.int16), busy[1500:]])
     assert np.array_equal(gpu.entropy_decode_gpu(oracle.rle_bytestream(black), black.shape[0]), black)
     assert gpu.last_decode_level() == 2
+
+
+def test_first_try_drops_candidates_that_cannot_start_a_block_and_the_second_try_catches_what_that_misses(gpu):
+    """The decoder's first try keeps, behind the first 192 bytes of a segment, only candidates whose first byte is below
+    0x10: a block of non-negative samples that holds anything has a non-zero DC, so its first header's run nibble is
+    zero (an empty block is the byte 0x00) -- most false candidates (a zero byte inside a block's bits) fail that, which
+    halves the candidates of a busy stream.  A stream with blocks that start otherwise (DC 0 beside non-zero AC: the
+    reference writes them for very dark content) lands on a dropped position, takes the second try (all candidates) and
+    decodes to the same coefficients; the working set then leaves the filter off for its next calls (such content pays
+    once in a while, not every time)."""
+    rng = np.random.default_rng(77)
+    usual = rng.integers(-200, 200, (6000, 64)).astype(np.int16)
+    usual[:, 0] = rng.integers(1, 1020, 6000)
+    dark = usual.copy()
+    dark[::50, 0] = 0                                            # DC 0, AC non-zero: first header (run >= 1, size)
+    gpu.lib().jpegx_host_pool_release()                          # fresh working sets: the pause counters start at zero
+    blob_u, blob_d = oracle.rle_bytestream(usual), oracle.rle_bytestream(dark)
+    assert np.array_equal(gpu.entropy_decode_gpu(blob_u, len(usual)), usual) and gpu.last_decode_level() == 0
+    assert np.array_equal(gpu.entropy_decode_gpu(blob_d, len(dark)), dark) and gpu.last_decode_level() == 1
+    for _ in range(3):                                           # the filter pauses: first try again, with every candidate
+        assert np.array_equal(gpu.entropy_decode_gpu(blob_d, len(dark)), dark) and gpu.last_decode_level() == 0
+    assert np.array_equal(gpu.entropy_decode_gpu(blob_u, len(usual)), usual) and gpu.last_decode_level() == 0
+    # damaged streams are still refused (one try later than without the filter), never accepted
+    bad = bytearray(blob_u)
+    bad[len(bad) // 2] ^= 0x40
+    try:
+        got = gpu.entropy_decode_gpu(bytes(bad), len(usual))
+    except gpu.JpegxError:
+        got = None
+    try:
+        want = oracle.rle_decode(bytes(bad), len(usual))
+    except oracle.RleStreamError:
+        want = None
+    assert got is None or (want is not None and np.array_equal(got, want))
 
 
 def test_decoder_state_stays_clean_across_streams_of_different_lengths(gpu):
