@@ -364,7 +364,7 @@ __host__ __device__ inline size_t dec_lds_bytes(int span_cap) { return (size_t)s
 
 __host__ __device__ inline size_t lds_bytes(int seg, int cmax)
 {
-    return (size_t)(FRONT + seg + TAIL) + 64 * 16 + 256 + (size_t)cmax * (4 + levels_of(cmax));   // cpos, J0: 16 bit; the upper levels: bytes
+    return (size_t)(FRONT + seg + TAIL) + 64 * 12 + 256 + (size_t)cmax * (4 + levels_of(cmax));   // lane records; advance table; cpos, J0: 16 bit; the upper levels: bytes
 }
 
 constexpr int MARK_STEPS = 5;               // steps of three codes between two way marks
@@ -536,7 +536,8 @@ __global__ __launch_bounds__(64) void k_seg_starts(const unsigned char *__restri
     const int win = FRONT + seg + TAIL;
     const int levels = levels_of(cmax);
     unsigned *sw = reinterpret_cast<unsigned *>(sm);
-    u32x4 *rec = reinterpret_cast<u32x4 *>(sm + win);                          // per lane: candidate mask (64 bit), candidates in front
+    struct LaneRec { unsigned lo, hi, front; };                                // per lane: candidate mask (64 bit), candidates in front
+    LaneRec *rec = reinterpret_cast<LaneRec *>(sm + win);
     unsigned char *tab = reinterpret_cast<unsigned char *>(rec + 64);
     unsigned short *cpos = reinterpret_cast<unsigned short *>(tab + 256);
     unsigned short *J = cpos + cmax;                                           // J0[c]: the candidate the block at c ends at, or a terminal code
@@ -593,7 +594,7 @@ __global__ __launch_bounds__(64) void k_seg_starts(const unsigned char *__restri
         if (lane >= d) incl += u;
     }
     const unsigned total = (unsigned)__shfl((int)incl, 63);
-    rec[lane] = u32x4{(unsigned)m, (unsigned)(m >> 32), incl - mine, 0u};
+    rec[lane] = LaneRec{(unsigned)m, (unsigned)(m >> 32), incl - mine};
     const bool overflow = total > (unsigned)cmax;
     if (!overflow) {
         unsigned at = incl - mine;
@@ -609,10 +610,10 @@ __global__ __launch_bounds__(64) void k_seg_starts(const unsigned char *__restri
     auto rank_of = [&](unsigned p, bool &is_cand) -> unsigned {
         const unsigned L = (p * inv) >> 20;
         const unsigned bit = p - L * (unsigned)stretch;
-        const u32x4 r = rec[L];
-        const unsigned long long mk = ((unsigned long long)r.y << 32) | r.x;
+        const LaneRec r = rec[L];
+        const unsigned long long mk = ((unsigned long long)r.hi << 32) | r.lo;
         is_cand = ((mk >> bit) & 1ull) != 0;
-        return r.z + (unsigned)__popcll(mk & ((1ull << bit) - 1ull));
+        return r.front + (unsigned)__popcll(mk & ((1ull << bit) - 1ull));
     };
     JPEGX_PHASE(1);
 
@@ -855,7 +856,9 @@ __global__ __launch_bounds__(256) void k_dec_blocks_lds(const unsigned char *__r
     // words go back to zero (k_seg_starts is done with them) and the other status block is cleared
     for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < nseg; i += gridDim.x * 256u) W.E[i] = 0u;
     if (blockIdx.x == 0 && threadIdx.x < 16) W.next_head[threadIdx.x] = 0u;
-    if (W.head[1] != 0 || W.head[2] != 0) return;        // refused, or handed to the general scheme: the block starts are not there
+    // the status words and the workgroup's segment in ONE round trip (the segment index is only meaningful when the status is clean)
+    const unsigned s0 = W.wave_seg[blockIdx.x], refused = W.head[1], handed_on = W.head[2];
+    if (refused != 0 || handed_on != 0) return;          // refused, or handed to the general scheme: the block starts are not there
     const int t = threadIdx.x, lane = t & 63, part = t >> 6;
     const int tile_idx = blockIdx.x, g0 = tile_idx * 64, g = g0 + lane;
 #ifdef JPEGX_DECODE_STATS
@@ -869,7 +872,6 @@ __global__ __launch_bounds__(256) void k_dec_blocks_lds(const unsigned char *__r
     unsigned char *dummy = tile + 64 * ROW + t * 4;
     unsigned *Fs = reinterpret_cast<unsigned *>(tile + 64 * ROW + 1024);       // [65] first-block indices from segment s0 on, [66] [67]: the span
     for (int i = t; i < 64 * ROW / 16; i += 256) *reinterpret_cast<u32x4 *>(tile + i * 16) = u32x4{0u, 0u, 0u, 0u};
-    const unsigned s0 = W.wave_seg[tile_idx];
     if (t <= 64) Fs[t] = s0 + t <= nseg ? W.F[s0 + t] : 0xFFFFFFFFu;
     __syncthreads();
     auto entry_of = [&](unsigned blk) -> u32x4 {          // what k_seg_starts left for block blk (>= the workgroup's first)
@@ -981,9 +983,11 @@ SegPlan seg_plan(size_t nbytes, long long nblocks, int level, int filter)
     if (level >= 1) k = 1;
     k = k < 1 ? 1 : (k > 16 ? 16 : k);
     p.seg = 256 * k;
-    p.cmax = 128;                    // candidates a segment's tables hold (a power of two): two and a half times the average
+    // candidates a segment's tables hold: about twice the average.  96 with the filter (the wave's LDS then stays at 6 KiB
+    // for 3840-byte segments: 26 waves per CU, so that the 6 204 waves of a 4096 x 4096 noise band run as ONE round)
+    p.cmax = p.filter ? 96 : 128;
     const char *fc = getenv("JPEGX_DECODE_CMAX");
-    if (fc && *fc) { p.cmax = 64; while (p.cmax < atoi(fc) && p.cmax < 128) p.cmax *= 2; }       // the upper table levels hold bytes: below 255
+    if (fc && *fc) { p.cmax = atoi(fc); p.cmax = p.cmax < 32 ? 32 : (p.cmax > 128 ? 128 : p.cmax); }    // the upper table levels hold bytes: below 255
     p.levels = seg::levels_of(p.cmax);
     p.nseg = (unsigned)((nbytes + p.seg - 1) / p.seg);
     // the block decoder's LDS span: 64 average blocks and half again (never more than 64 blocks can be: 64 x 185 bytes)
