@@ -316,6 +316,71 @@ def config_u8(jpegx, kind, iters, verify, planes=16):
     return res
 
 
+def config_entropy_band(jpegx, kind, iters, verify):
+    """ONE 4096 x 4096 uint8 band through the kernels compress_band / decompress_band launch for it, everything resident
+    in HBM, launched alone and back to back on one stream (HIP events): forward with block sizes -> scan -> two-lane
+    emitter, and device decoder (three launches on the caller's buffers, jpegx_entropy_decode, + the fill that clears
+    its state: the pooled host jobs keep theirs clean and skip it) -> uint8 inverse.  A single band is 4096 waves per
+    kernel: these chains are latency, not throughput; us per band."""
+    n = 4096
+    L = jpegx.lib()
+    f32 = jpegx.DeviceBuffer(n * n * 4)
+    jpegx.generate_plane_device(f32.ptr, n, n, kind, seed=0, plane=0)
+    band = f32.download((n, n), np.float32).astype(np.uint8)
+    f32.free()
+    blocks = (n // 8) * (n // 8)
+    u8, zz, zz2, rec = jpegx.DeviceBuffer(n * n), jpegx.DeviceBuffer(blocks * 128), jpegx.DeviceBuffer(blocks * 128), jpegx.DeviceBuffer(n * n)
+    u8.upload(band)
+    ws = jpegx.DeviceBuffer(int(L.jpegx_entropy_workspace_bytes(blocks)))
+    bb, wb_, hb = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+    L.jpegx_internal_entropy_views.argtypes = [ctypes.c_void_p, ctypes.c_longlong] + [ctypes.POINTER(ctypes.c_void_p)] * 3
+    L.jpegx_internal_entropy_views.restype = None
+    L.jpegx_internal_entropy_views(ws.ptr, blocks, ctypes.byref(bb), ctypes.byref(wb_), ctypes.byref(hb))
+    L.jpegx_internal_forward_u8_sized.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_ssize_t, ctypes.c_int, ctypes.c_int, ctypes.c_double,
+                                                  ctypes.c_uint, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    L.jpegx_internal_forward_u8_sized.restype = ctypes.c_int
+    L.jpegx_internal_entropy_scan.argtypes = [ctypes.c_longlong, ctypes.c_void_p, ctypes.c_void_p]
+    L.jpegx_internal_entropy_scan.restype = ctypes.c_int
+    L.jpegx_internal_entropy_emit2.argtypes = [ctypes.c_void_p, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    L.jpegx_internal_entropy_emit2.restype = ctypes.c_int
+    out = jpegx.DeviceBuffer(blocks * 188 + 64)                  # a block's code string is at most 185 bytes
+
+    def compress_chain():
+        jpegx.check(L.jpegx_internal_forward_u8_sized(u8.ptr, n, n, n, 1, jpegx.Q_QTABLE, 0.0, 0, zz.ptr, bb, wb_, hb, None), "forward_u8_sized")
+        jpegx.check(L.jpegx_internal_entropy_scan(blocks, ws.ptr, None), "entropy_scan")
+        jpegx.check(L.jpegx_internal_entropy_emit2(zz.ptr, blocks, ws.ptr, out.ptr, None), "entropy_emit2")
+    compress_chain()
+    total = ctypes.c_ulonglong(0)
+    jpegx.check(L.jpegx_entropy_total(ws.ptr, ctypes.byref(total), None), "entropy_total")
+    nbytes = int(total.value)
+    jpegx.check(L.jpegx_memset(out.ptr + nbytes, 0, 64, None), "memset")        # the decoder reads up to 16 zero bytes behind the stream
+    dws = jpegx.DeviceBuffer(int(L.jpegx_entropy_decode_workspace_bytes(nbytes, blocks)))
+
+    def decompress_chain():
+        jpegx.check(L.jpegx_entropy_decode(out.ptr, nbytes, blocks, dws.ptr, zz2.ptr, 0, None), "entropy_decode")
+        jpegx.check(L.jpegx_inverse_fused_u8_inflated(zz2.ptr, n, n, jpegx.Q_QTABLE, 0.0, 0, 1, rec.ptr, n, None), "inverse_u8")
+    decompress_chain()
+    jpegx.check(L.jpegx_entropy_decode_status(dws.ptr, None), "entropy_decode_status")
+    us_c = _timed_launches(jpegx, compress_chain, iters) * 1e3
+    us_d = _timed_launches(jpegx, decompress_chain, iters) * 1e3
+    res = {"blocks": blocks, "stream_bytes": nbytes,
+           "compress_chain_us": round(us_c, 1), "compress_launches": 3,
+           "decompress_chain_us": round(us_d, 1), "decompress_launches": 5,
+           "note": "forward_u8 + sizes, scan, emit2 | state fill, k_seg_starts, k_seg_scan, k_dec_blocks_lds, inverse_u8; one band launched alone"}
+    if verify:
+        import oracle
+        want = oracle.forward_f32(band[:512].astype(np.float32), "qtable")
+        got = zz2.download((64, n // 8, 64), np.int16)
+        blob = out.download((nbytes,), np.uint8).tobytes()
+        back = rec.download((512, n), np.uint8)
+        head = oracle.rle_bytestream(want)
+        res["verified_vs_oracle"] = bool(np.array_equal(got, want) and blob[:len(head)] == head and
+                                         np.array_equal(back, np.clip(oracle.inverse_i16(want, "qtable"), 0, 255).astype(np.uint8)))
+    for b in (u8, zz, zz2, rec, ws, out, dws):
+        b.free()
+    return res
+
+
 # --------------------------------------------------------------------------------------------------
 GATHER_FAILED_STATUS = 3       # exit status of every rank when the exchange (gather legs) failed or timed out
 
@@ -568,7 +633,8 @@ def run(args, rank, local_rank, world, ctl, emit):
             b_in.free()
             iters = max(10, min(50, args.steps))
             cfg = {}
-            for name, fn in (("c3_8192_ycbcr420_forward", config3), ("c4_4096_round_trip", config4), ("u8_band_kernels", config_u8)):
+            for name, fn in (("c3_8192_ycbcr420_forward", config3), ("c4_4096_round_trip", config4), ("u8_band_kernels", config_u8),
+                             ("entropy_band_chain", config_entropy_band)):
                 cfg[name] = {}
                 for kind in ("noise", "smooth"):
                     try:

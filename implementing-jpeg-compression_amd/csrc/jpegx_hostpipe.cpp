@@ -848,6 +848,62 @@ int jpegx_host_decompress_image(const uint8_t *const *h_bytes, const size_t *nby
 
 extern "C" int jpegx_internal_last_decode_level(void) { return t_last_decode_level; }
 
+// ---- the device decoder on the caller's device buffers (include/jpegx.h) -------------------------------------------
+// workspace: [state of the larger plan, rounded up to 256 bytes][scratch of the larger plan]; the state is cleared by
+// every call (the pooled jobs above keep theirs clean from call to call instead: one fill launch less)
+namespace {
+size_t decode_state_span(size_t nbytes, long long nblocks)
+{
+    size_t m = 0;
+    for (int level = 0; level < 2; ++level)
+        for (int filter = -1; filter <= 0; ++filter) {
+            const jpegx_decode::SegPlan p = jpegx_decode::seg_plan(nbytes, nblocks, level, filter);
+            if (p.state_bytes > m) m = p.state_bytes;
+        }
+    return (m + 255) & ~(size_t)255;
+}
+}  // namespace
+
+extern "C" size_t jpegx_entropy_decode_workspace_bytes(size_t nbytes, long long nblocks)
+{
+    if (nbytes == 0 || nblocks <= 0) return 0;
+    size_t scratch = 0;
+    for (int level = 0; level < 2; ++level)
+        for (int filter = -1; filter <= 0; ++filter) {
+            const jpegx_decode::SegPlan p = jpegx_decode::seg_plan(nbytes, nblocks, level, filter);
+            if (p.ws_bytes > scratch) scratch = p.ws_bytes;
+        }
+    return decode_state_span(nbytes, nblocks) + scratch + 256;
+}
+
+extern "C" int jpegx_entropy_decode(const uint8_t *d_bytes, size_t nbytes, long long nblocks, void *d_workspace, int16_t *d_zz,
+                                    int level, jpegx_stream_t stream)
+{
+    if (!d_bytes || !d_workspace || !d_zz) return fail(JPEGX_E_INVALID, "null device pointer");
+    if (nblocks <= 0 || nblocks > 0x7FFFFFC0LL) return fail(JPEGX_E_INVALID, "block count must be in 1 .. 2^31-64");
+    if (nbytes == 0 || nbytes >= 0xFFFFFFF0ull) return fail(JPEGX_E_INVALID, "entropy stream empty or beyond 4 GiB");
+    if (level < 0 || level > 1) return fail(JPEGX_E_UNSUPPORTED, "levels 0 and 1 run on caller buffers; the whole-stream scheme is jpegx_host_entropy_decode_gpu's");
+    if ((reinterpret_cast<uintptr_t>(d_workspace) & 255u) != 0) return fail(JPEGX_E_INVALID, "workspace must be 256-byte aligned");
+    const jpegx_decode::SegPlan plan = jpegx_decode::seg_plan(nbytes, nblocks, level);
+    if (!plan.ok) return fail(JPEGX_E_UNSUPPORTED, "stream too long for the segmented decoder");
+    const size_t state_span = decode_state_span(nbytes, nblocks);
+    unsigned char *w = static_cast<unsigned char *>(d_workspace);
+    jpegx_decode::enqueue_segmented(d_bytes, nbytes, nblocks, plan, w, state_span, true, 0, w + state_span, d_zz, (hipStream_t)stream);
+    HP_TRY(hipGetLastError());
+    return JPEGX_OK;
+}
+
+extern "C" int jpegx_entropy_decode_status(const void *d_workspace, jpegx_stream_t stream)
+{
+    if (!d_workspace) return fail(JPEGX_E_INVALID, "null device pointer");
+    unsigned head[16] = {0};
+    HP_TRY(hipMemcpyAsync(head, d_workspace, 64, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    if (head[2] != 0) return 1;
+    if (head[1] != 0) return fail(JPEGX_E_INVALID, "entropy stream is not a sequence of well-formed blocks (device decoder)");
+    return JPEGX_OK;
+}
+
 // bytes -> int16 [nblocks][64] on the device, host arrays in and out (what jpegx_host_entropy_decode does on the CPU)
 int jpegx_host_entropy_decode_gpu(const uint8_t *h_bytes, size_t nbytes, long long nblocks, int16_t *h_zz)
 {

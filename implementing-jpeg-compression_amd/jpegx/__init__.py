@@ -133,6 +133,9 @@ SIGNATURES = {
     "jpegx_entropy_emit": [_vp, _c.c_longlong, _vp, _vp, _vp],
     "jpegx_host_entropy_encode": [_vp, _c.c_longlong, _vp, _sz, _c.POINTER(_sz)],
     "jpegx_host_entropy_decode": [_vp, _sz, _c.c_longlong, _vp],
+    "jpegx_entropy_decode_workspace_bytes": [_sz, _c.c_longlong],
+    "jpegx_entropy_decode": [_vp, _sz, _c.c_longlong, _vp, _vp, _int, _vp],
+    "jpegx_entropy_decode_status": [_vp, _vp],
     "jpegx_comm_available": [],
     "jpegx_comm_unique_id": [_vp],
     "jpegx_comm_create": [_c.POINTER(_vp), _int, _int, _vp],
@@ -150,7 +153,7 @@ for _name in ("jpegx_malloc", "jpegx_free", "jpegx_stream_create", "jpegx_genera
               "jpegx_host_decompress_plane_i64", "jpegx_host_decompress_image", "jpegx_host_entropy_decode_gpu",
               "jpegx_host_pool_release", "jpegx_comm_create_deadline"):
     SIGNATURES[_name + "_on"] = [_int] + SIGNATURES[_name]
-RESTYPES = {"jpegx_entropy_workspace_bytes": _sz}   # everything else returns int
+RESTYPES = {"jpegx_entropy_workspace_bytes": _sz, "jpegx_entropy_decode_workspace_bytes": _sz}   # everything else returns int
 
 
 def lib():
@@ -814,6 +817,22 @@ def decompress_plane_i64(blob, height, width, block_size, mode, param, rows, col
                                                 int(block_size), mode_of(mode), float(param), out.ctypes.data, int(rows), int(cols)),
           "jpegx_host_decompress_plane_i64")
     return out
+
+
+def entropy_decode_device(d_bytes, nbytes, nblocks, d_workspace, d_zz, stream=None):
+    """The device decoder on the caller's device buffers (jpegx_entropy_decode / _status): first try, then -- if that
+    could not take the stream -- the second; returns the level that took it.  d_bytes: the stream with 16 zero bytes
+    behind it; d_workspace: jpegx_entropy_decode_workspace_bytes(nbytes, nblocks) bytes, 256-byte aligned.  Raises
+    JpegxError for a malformed stream, and for the (degenerate) streams only the whole-stream scheme takes."""
+    L = lib()
+    for level in (0, 1):
+        check(L.jpegx_entropy_decode(d_bytes, int(nbytes), int(nblocks), d_workspace, d_zz, level, stream), "jpegx_entropy_decode")
+        rc = L.jpegx_entropy_decode_status(d_workspace, stream)
+        if rc == 0:
+            return level
+        if rc != 1:
+            check(rc, "jpegx_entropy_decode_status")
+    raise JpegxError("jpegx_entropy_decode: neither level took the stream (more block starts than a segment's tables hold)")
 
 
 def entropy_decode(blob, nblocks):

@@ -245,6 +245,22 @@ int jpegx_entropy_emit(const int16_t *d_zz, long long nblocks, const void *d_wor
 int jpegx_host_entropy_encode(const int16_t *h_zz, long long nblocks, uint8_t *h_out, size_t cap,
                               size_t *nbytes);
 
+/* Inverse of the entropy stage ON THE DEVICE, device pointers in and out (what jpegx_host_entropy_decode_gpu and the
+ * jpegx_host_decompress_* jobs run on their pooled buffers): RleBytestream.invert (pipeline/rle_byte_stream.py:61-88) +
+ * RunLengthEncoding.invert (pipeline/run_length_encoding.py:66-97) for dct_size 8, bytes -> int16 [nblocks][64], three
+ * kernel launches, no host round trip.  d_bytes must be readable (and zero) for 16 bytes behind the stream.
+ * `level` 0: segments sized from the stream's average block length, candidates that cannot start a block dropped;
+ * `level` 1: 256-byte segments, every candidate (the second try).  jpegx_entropy_decode only enqueues (it clears the
+ * workspace's state first); jpegx_entropy_decode_status synchronises the stream and answers JPEGX_OK, 1 = "this level
+ * could not take the stream, enqueue the next one" (a stretch far denser in blocks than the average, or a block the
+ * first try's filter dropped), or JPEGX_E_INVALID for a stream that is not a sequence of well-formed blocks of this
+ * plane (the sequential host parser names the fault).  After level 1 answers 1 (blocks of one byte each: more
+ * candidates than any segment's tables hold) the whole-stream scheme of the host conveniences is what is left. */
+size_t jpegx_entropy_decode_workspace_bytes(size_t nbytes, long long nblocks);
+int jpegx_entropy_decode(const uint8_t *d_bytes, size_t nbytes, long long nblocks, void *d_workspace, int16_t *d_zz,
+                         int level, jpegx_stream_t stream);
+int jpegx_entropy_decode_status(const void *d_workspace, jpegx_stream_t stream);
+
 /* Inverse of the entropy stage, ON THE HOST (sequential parse, as in the reference):
  * RleBytestream.invert (pipeline/rle_byte_stream.py:61-88) + RunLengthEncoding.invert
  * (pipeline/run_length_encoding.py:66-97) for dct_size 8: bytes -> int16 [nblocks][64].        */

@@ -209,6 +209,48 @@ def test_first_try_drops_candidates_that_cannot_start_a_block_and_the_second_try
     assert got is None or (want is not None and np.array_equal(got, want))
 
 
+def test_device_decoder_on_caller_buffers(gpu, golden):
+    """jpegx_entropy_decode / _status: the decoder on device pointers the caller owns (stream in, int16 zigzag blocks out,
+    a workspace sized by jpegx_entropy_decode_workspace_bytes) -- what an integrator uses who keeps the streams on the
+    device, e.g. behind the RCCL gather.  Same coefficients as the oracle's decoder; the second try takes what the first
+    hands on; malformed streams are refused."""
+    rng = np.random.default_rng(8)
+    streams = [golden("noise64")["zz_qtable"].reshape(-1, 64), golden("smooth64")["zz_none"].reshape(-1, 64)]
+    z = rng.integers(-150, 150, (20000, 64)).astype(np.int16)
+    z[:, 0] = rng.integers(1, 900, len(z))
+    streams.append(z)
+    dark = z[:3000].copy()
+    dark[::40, 0] = 0                                           # blocks the first try's filter drops: level 1 takes the stream
+    streams.append(dark)
+    L = gpu.lib()
+    for i, zz in enumerate(streams):
+        blob = oracle.rle_bytestream(zz.reshape(len(zz), 1, 64))
+        want = oracle.rle_decode(blob, len(zz))
+        d_bytes = gpu.DeviceBuffer(len(blob) + 16)
+        d_bytes.upload(np.frombuffer(blob + bytes(16), dtype=np.uint8))
+        ws = gpu.DeviceBuffer(int(L.jpegx_entropy_decode_workspace_bytes(len(blob), len(zz))))
+        d_zz = gpu.DeviceBuffer(len(zz) * 128)
+        for rep in range(2):                                    # the same workspace again: every call clears its state itself
+            level = gpu.entropy_decode_device(d_bytes.ptr, len(blob), len(zz), ws.ptr, d_zz.ptr)
+            assert level == (1 if i == 3 else 0), (i, level)
+            assert np.array_equal(d_zz.download((len(zz), 64), np.int16), want), i
+        bad = bytearray(blob + bytes(16))
+        bad[len(blob) // 2] ^= 0x10
+        d_bytes.upload(np.frombuffer(bytes(bad), dtype=np.uint8))
+        try:
+            gpu.entropy_decode_device(d_bytes.ptr, len(blob), len(zz), ws.ptr, d_zz.ptr)
+            got = d_zz.download((len(zz), 64), np.int16)
+        except gpu.JpegxError:
+            got = None
+        try:
+            ref = oracle.rle_decode(bytes(bad[:len(blob)]), len(zz))
+        except oracle.RleStreamError:
+            ref = None
+        assert got is None or (ref is not None and np.array_equal(got, ref)), i
+    with pytest.raises(gpu.JpegxError):
+        gpu.check(L.jpegx_entropy_decode(d_bytes.ptr, 10, 1, ws.ptr, d_zz.ptr, 2, None), "level 2")
+
+
 def test_decoder_state_stays_clean_across_streams_of_different_lengths(gpu):
     """The segmented decoder keeps its status blocks and exit words zero from call to call by itself (no memset launch per
     call) and its other arrays move with the segment count: a short stream's arrays must not end up where a later,
