@@ -62,6 +62,9 @@ JPEGX_ON(jpegx_entropy_total, (int device, const void *d_workspace, unsigned lon
 JPEGX_ON(jpegx_entropy_block_sizes, (int device, const void *d_workspace, long long nblocks, uint32_t *h_sizes, jpegx_stream_t stream), (d_workspace, nblocks, h_sizes, stream))
 JPEGX_ON(jpegx_entropy_emit, (int device, const int16_t *d_zz, long long nblocks, const void *d_workspace, uint8_t *d_out, jpegx_stream_t stream),
          (d_zz, nblocks, d_workspace, d_out, stream))
+JPEGX_ON(jpegx_entropy_decode, (int device, const uint8_t *d_bytes, size_t nbytes, long long nblocks, void *d_workspace, int16_t *d_zz, int level, jpegx_stream_t stream),
+         (d_bytes, nbytes, nblocks, d_workspace, d_zz, level, stream))
+JPEGX_ON(jpegx_entropy_decode_status, (int device, const void *d_workspace, jpegx_stream_t stream), (d_workspace, stream))
 JPEGX_ON(jpegx_host_compress_begin, (int device, const void *h_plane, int elem_size, int H, int W, ptrdiff_t pitch, int bs, int mode, double param, size_t *nbytes),
          (h_plane, elem_size, H, W, pitch, bs, mode, param, nbytes))
 JPEGX_ON(jpegx_host_compress_image, (int device, const void *const *h_planes, int nbands, int elem_size, int H, int W, ptrdiff_t pitch, int bs, int mode, double param, const void *prefix, size_t prefix_len, int length_prefixes, jpegx_alloc_fn alloc, void *user, size_t *nbytes),

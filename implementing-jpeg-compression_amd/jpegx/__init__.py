@@ -149,7 +149,7 @@ SIGNATURES = {
 for _name in ("jpegx_malloc", "jpegx_free", "jpegx_stream_create", "jpegx_generate_plane", "jpegx_forward_fused_pooled",
               "jpegx_forward_fused_u8", "jpegx_forward_fused_f64", "jpegx_forward_fused_planes", "jpegx_mean_pool_f64",
               "jpegx_inverse_fused_u8_inflated", "jpegx_entropy_sizes", "jpegx_entropy_total", "jpegx_entropy_block_sizes",
-              "jpegx_entropy_emit", "jpegx_host_compress_begin", "jpegx_host_compress_image", "jpegx_host_compress_image_packed", "jpegx_host_decompress_plane",
+              "jpegx_entropy_emit", "jpegx_entropy_decode", "jpegx_entropy_decode_status", "jpegx_host_compress_begin", "jpegx_host_compress_image", "jpegx_host_compress_image_packed", "jpegx_host_decompress_plane",
               "jpegx_host_decompress_plane_i64", "jpegx_host_decompress_image", "jpegx_host_entropy_decode_gpu",
               "jpegx_host_pool_release", "jpegx_comm_create_deadline"):
     SIGNATURES[_name + "_on"] = [_int] + SIGNATURES[_name]

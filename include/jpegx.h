@@ -405,6 +405,9 @@ int jpegx_entropy_block_sizes_on(int device, const void *d_workspace, long long 
                                  jpegx_stream_t stream);
 int jpegx_entropy_emit_on(int device, const int16_t *d_zz, long long nblocks, const void *d_workspace, uint8_t *d_out,
                           jpegx_stream_t stream);
+int jpegx_entropy_decode_on(int device, const uint8_t *d_bytes, size_t nbytes, long long nblocks, void *d_workspace,
+                            int16_t *d_zz, int level, jpegx_stream_t stream);
+int jpegx_entropy_decode_status_on(int device, const void *d_workspace, jpegx_stream_t stream);
 int jpegx_host_compress_begin_on(int device, const void *h_plane, int elem_size, int H, int W, ptrdiff_t pitch, int bs,
                                  int mode, double param, size_t *nbytes);
 int jpegx_host_compress_image_on(int device, const void *const *h_planes, int nbands, int elem_size, int H, int W,
