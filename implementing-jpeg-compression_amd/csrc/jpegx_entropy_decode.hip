@@ -982,6 +982,27 @@ SegPlan seg_plan(size_t nbytes, long long nblocks, int level, int filter)
     // round trip and the whole-stream scheme
     if (level >= 1) k = 1;
     k = k < 1 ? 1 : (k > 16 ? 16 : k);
+    if (level == 0 && !(force && *force)) {
+        // One round of waves if the stream allows it: k_seg_starts takes as many wave lives as it has rounds (its waves run in
+        // step), so a segment size whose waves all fit the chip at once -- with a margin: 831 waves on an XCD's 832 slots
+        // measured as two rounds -- beats a neighbouring size that needs a few more.  Waves per CU from the wave's LDS
+        // (allocated in steps taken as 1280 bytes, the coarser of what the measurements allow), at most 32.
+        static const int ncu = [] { int v = 0, dev = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256; return v; }();
+        const int cmax_l0 = p.filter ? 96 : 128;
+        auto margin = [&](int kk) {
+            const size_t lds = (seg::lds_bytes(256 * kk, cmax_l0) + 1279) / 1280 * 1280;
+            const size_t per_cu = 163840 / lds > 32 ? 32 : 163840 / lds;
+            const double slots = (double)ncu * (double)per_cu, waves = (double)((nbytes + 256 * (size_t)kk - 1) / (256 * (size_t)kk));
+            return 1.0 - waves / slots;
+        };
+        if (margin(k) < 0.03) {
+            int best = k;
+            double best_margin = 0.03;
+            for (int kk : {k + 1, k - 1, k + 2, k - 2})
+                if (kk >= 1 && kk <= 16 && per_byte * 256.0 * kk <= 56.0 && margin(kk) > best_margin) { best = kk; best_margin = margin(kk); }
+            k = best;
+        }
+    }
     p.seg = 256 * k;
     // candidates a segment's tables hold: about twice the average.  96 with the filter (the wave's LDS then stays at 6 KiB
     // for 3840-byte segments: 26 waves per CU, so that the 6 204 waves of a 4096 x 4096 noise band run as ONE round)
