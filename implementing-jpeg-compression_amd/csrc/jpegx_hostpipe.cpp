@@ -168,6 +168,7 @@ struct PoolLock {     // scope form
 int ensure_streams(DevicePool *pool, bool image)
 {
     if (!pool->stream) HP_TRY(hipStreamCreateWithFlags(&pool->stream, hipStreamNonBlocking));
+    if (!pool->ev[0]) HP_TRY(hipEventCreateWithFlags(&pool->ev[0], hipEventDisableTiming));      // band jobs wait on it for the stream's size
     if (image) {
         for (int i = 0; i < 2; ++i)
             if (!pool->aux[i]) HP_TRY(hipStreamCreateWithFlags(&pool->aux[i], hipStreamNonBlocking));
@@ -414,14 +415,23 @@ int jpegx_host_compress_begin(const void *h_plane, int elem_size, int H, int W, 
     if (elem_size != 1 && (rc = pool->h_in.ensure((size_t)H * bs * W * bs))) return bail(rc);
     BandSlot &slot = pool->slot[0];
     hipStream_t st = pool->stream;
+    // The emitter goes into the stream BEHIND the size read-back without waiting for it: the device does not idle while the
+    // host learns the byte count (a 16-byte copy, a wake-up and a launch: ~25 us), and the emitter refuses by itself when
+    // the sizes pass flagged an amplitude.  Its destination is therefore sized for the worst case (185 bytes per block).
+    const long long nblocks = (long long)(H / 8) * (W / 8);
+    if ((rc = slot.d_out.ensure((size_t)nblocks * 188 + 64)) || (rc = pool->h_head.ensure(16 * MAX_BANDS))) return bail(rc);
     if ((rc = enqueue_front(pool, slot, static_cast<uint8_t *>(pool->h_in.p), h_plane, elem_size, H, W, pitch, bs, mode, param, st)))
         return bail(rc);
+    unsigned long long *head = static_cast<unsigned long long *>(pool->h_head.p);
+    if (hipMemcpyAsync(head, slot.d_ws.p, 16, hipMemcpyDeviceToHost, st) != hipSuccess || hipEventRecord(pool->ev[0], st) != hipSuccess) {
+        (void)hipStreamSynchronize(st);
+        return bail(fail(JPEGX_E_HIP, "device to host copy failed"));
+    }
+    rc = enqueue_emit(slot, nblocks, static_cast<uint8_t *>(slot.d_out.p), st);
+    if (hipEventSynchronize(pool->ev[0]) != hipSuccess) { (void)hipStreamSynchronize(st); return bail(fail(JPEGX_E_HIP, "hipEventSynchronize failed")); }
+    if (rc) { (void)hipStreamSynchronize(st); return bail(rc); }
     unsigned long long total = 0;
-    if ((rc = jpegx_entropy_total(slot.d_ws.p, &total, st))) return bail(rc);      // synchronises
-    if ((rc = slot.d_out.ensure(total ? (size_t)total : 1))) return bail(rc);
-    const long long nblocks = (long long)(H / 8) * (W / 8);
-    if ((rc = enqueue_emit(slot, nblocks, static_cast<uint8_t *>(slot.d_out.p), st)))
-        return bail(rc);
+    if ((rc = head_verdict(head, &total))) { (void)hipStreamSynchronize(st); return bail(rc); }
     pool->open = true;
     pool->out_bytes = (size_t)total;
     *nbytes = (size_t)total;
